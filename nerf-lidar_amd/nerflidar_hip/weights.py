@@ -1,0 +1,90 @@
+"""Parameter tables for the render path, keyed exactly like the reference's `state_dict`.
+
+Key names follow `Model.state_dict()` of ZI/models.py (`nerf_mlp.encoder.embeddings`,
+`nerf_mlp.density_layer.0.weight`, `nerf_mlp.lin_second_stage_3.bias`, `prop_mlp_0.encoder...`),
+so a released checkpoint's `state_dict` can be passed to `Model.load_state_dict` unchanged
+(ZI/checkpoints.py:26-55).  Values are float32 numpy arrays.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import synth
+from .config import MLPConfig, ModelConfig
+
+
+def grid_layout(cfg: MLPConfig, input_dim: int = 3, align_corners: bool = False):
+    """Level offset table of Z/gridencoder/grid.py:122-142.
+
+    Returns (offsets int32 [L+1], grid_sizes int32 [L], per_level_scale float).
+    """
+    L = cfg.grid_num_levels
+    # grid.py:105-106 (desired_resolution overrides per_level_scale)
+    per_level_scale = np.exp2(np.log2(cfg.grid_disired_resolution / cfg.grid_base_resolution) / (L - 1)) \
+        if L > 1 else 1.0
+    max_params = 2 ** cfg.grid_log2_hashmap_size
+    offsets, sizes, off = [], [], 0
+    for i in range(L):
+        res = int(np.ceil(cfg.grid_base_resolution * per_level_scale ** i))
+        res = res if align_corners else res + 1
+        n = min(max_params, res ** input_dim)
+        n = int(np.ceil(n / 8) * 8)
+        sizes.append(res)
+        offsets.append(off)
+        off += n
+    offsets.append(off)
+    return np.asarray(offsets, np.int32), np.asarray(sizes, np.int32), float(per_level_scale)
+
+
+def mlp_param_shapes(cfg: MLPConfig) -> List[Tuple[str, Tuple[int, int], bool]]:
+    """(name, (out,in), kaiming) for every Linear of ZI/models.py:MLP.__init__ on the path."""
+    feat = cfg.grid_num_levels * cfg.grid_level_dim
+    out = [("density_layer.0", (64, feat), False),
+           ("density_layer.2", (1 if cfg.disable_rgb else cfg.bottleneck_width, 64), False)]
+    if cfg.disable_rgb:
+        return out
+    in_rgb = cfg.bottleneck_width + cfg.dim_dir_enc  # models.py:920-926
+    last = in_rgb
+    for i in range(cfg.net_depth_viewdirs):  # models.py:939-950
+        out.append((f"lin_second_stage_{i}", (cfg.net_width_viewdirs, last), True))
+        last = cfg.net_width_viewdirs
+        if i == cfg.skip_layer_dir:
+            last += in_rgb
+    out.append(("rgb_layer", (cfg.num_rgb_channels, last), False))
+    if cfg.use_semantic and not cfg.no_sem_layer:  # models.py:954-957
+        out += [("sem_layer.0", (64, cfg.bottleneck_width), False), ("sem_layer.2", (cfg.class_num, 64), False)]
+    if cfg.use_intensity:  # models.py:958-961
+        out += [("intensity_layer.0", (64, cfg.bottleneck_width), False), ("intensity_layer.2", (1, 64), False)]
+    return out
+
+
+def mlp_names(mc: ModelConfig) -> List[Tuple[str, MLPConfig]]:
+    names = [(f"prop_mlp_{i}", mc.prop_cfg(i)) for i in range(mc.num_levels - 1)]
+    names.append(("nerf_mlp", mc.nerf_mlp))
+    return names
+
+
+def synth_state_dict(mc: ModelConfig, seed: int = 0, table_std: float = 1e-4,
+                     head_gain: float = 1.0) -> Dict[str, np.ndarray]:
+    """Seeded random-init parameters with the reference's init ranges.
+
+    table_std=1e-4 is the reference init (grid.py:101); SURVEY 8d's "trained-like" set uses 0.1
+    so that densities are non-degenerate.  head_gain scales density_layer.2 so that raw density
+    spans a useful range with random weights (1.0 = reference init).
+    """
+    sd: Dict[str, np.ndarray] = {}
+    for prefix, cfg in mlp_names(mc):
+        offsets, sizes, _ = grid_layout(cfg)
+        sd[f"{prefix}.encoder.embeddings"] = synth.table_init(
+            seed, f"{prefix}.encoder.embeddings", int(offsets[-1]), cfg.grid_level_dim, table_std)
+        sd[f"{prefix}.encoder.offsets"] = offsets
+        sd[f"{prefix}.encoder.grid_sizes"] = sizes
+        for name, (o, i), kaiming in mlp_param_shapes(cfg):
+            w, b = synth.linear_init(seed, f"{prefix}.{name}", o, i, kaiming)
+            if name == "density_layer.2" and head_gain != 1.0:
+                w = (w * np.float32(head_gain)).astype(np.float32)
+            sd[f"{prefix}.{name}.weight"] = w
+            sd[f"{prefix}.{name}.bias"] = b
+    return sd

@@ -1,0 +1,311 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own Python.
+
+Runs only in the build container (needs /root/reference; the GPU box never has it).  It imports
+/root/reference/NeRF_LiDAR/zipnerf/internal/{math,stepfun,render,coord,models}.py unmodified,
+with in-process stubs for the third-party modules that are not installed here (gin,
+torch_scatter, pyquaternion, skimage, cv2, accelerate is present) and with `gridencoder`
+provided by the CPU restatement of the CUDA kernel (oracle/grid_oracle.c) -- the one piece of the
+path that has no runnable reference.  gin bindings are applied by hand as class attributes
+(SURVEY Appendix B).
+
+Only DATA is written: inputs, seeds/config names and the reference's outputs, as small .npz
+files.  Weights are not stored: they are regenerated from (seed, config) by
+nerflidar_hip.weights.synth_state_dict, which this script also uses to fill the reference model.
+
+Usage:  python tests/golden/make_golden.py            (from the repo root)
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")  # coord.contract_mean_std is @torch.compile
+sys.dont_write_bytecode = True
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/NeRF_LiDAR/zipnerf"
+sys.path.insert(0, os.path.join(ROOT, "nerf-lidar_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from oracle import nlr_oracle as orc
+from nerflidar_hip import config as nconfig, lidar as nlidar, weights as nweights, synth
+
+
+# ---------------------------------------------------------------------------- stubs
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def _configurable(*args, **kwargs):
+    if len(args) == 1 and callable(args[0]) and not kwargs:
+        return args[0]
+    return lambda f: f
+
+
+gin = _stub("gin", configurable=_configurable, add_config_file_search_path=lambda *a, **k: None,
+            config_scope=None, REQUIRED=None)
+gin.config = _stub("gin.config", external_configurable=lambda *a, **k: None)
+_stub("torch_scatter", segment_coo=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError()))
+_stub("pyquaternion", Quaternion=object)
+sk = _stub("skimage")
+sk.metrics = _stub("skimage.metrics", structural_similarity=None, peak_signal_noise_ratio=None)
+_stub("cv2")
+
+
+class RefGridEncoder(nn.Module):
+    """`gridencoder.GridEncoder` for the reference import: constructor/attrs of grid.py:96-149,
+    forward through the CPU restatement of kernel_grid."""
+
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
+                 log2_hashmap_size=19, desired_resolution=None, gridtype='hash', align_corners=False,
+                 interpolation='linear', init_std=1e-4):
+        super().__init__()
+        if desired_resolution is not None:
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
+        self.per_level_scale, self.base_resolution = per_level_scale, base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype_id = {'hash': 0, 'tiled': 1}[gridtype]
+        self.interp_id = {'linear': 0, 'smoothstep': 1}[interpolation]
+        self.align_corners, self.init_std = align_corners, init_std
+        offsets, sizes, off = [], [], 0
+        for i in range(num_levels):
+            res = int(np.ceil(base_resolution * per_level_scale ** i))
+            res = res if align_corners else res + 1
+            n = min(2 ** log2_hashmap_size, res ** input_dim)
+            n = int(np.ceil(n / 8) * 8)
+            sizes.append(res); offsets.append(off); off += n
+        offsets.append(off)
+        self.register_buffer('offsets', torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        idx = torch.empty(off, dtype=torch.long)
+        for i in range(num_levels):
+            idx[offsets[i]:offsets[i + 1]] = i
+        self.register_buffer('idx', idx)
+        self.register_buffer('grid_sizes', torch.from_numpy(np.array(sizes, dtype=np.int32)))
+        self.embeddings = nn.Parameter(torch.empty(off, level_dim).uniform_(-init_std, init_std))
+
+    def forward(self, inputs, bound=1):
+        x01 = (inputs + bound) / (2 * bound)
+        prefix = list(x01.shape[:-1])
+        flat = x01.reshape(-1, self.input_dim).detach().contiguous().numpy()
+        out, _ = orc.grid_encode_c(flat, self.embeddings.detach().numpy(), self.offsets.numpy(),
+                                   float(np.log2(self.per_level_scale)), self.base_resolution,
+                                   self.gridtype_id, self.align_corners, self.interp_id)
+        out = torch.from_numpy(out).permute(1, 0, 2).reshape(flat.shape[0], self.output_dim)
+        return out.view(prefix + [self.output_dim])
+
+
+_stub("gridencoder", GridEncoder=RefGridEncoder)
+sys.path.insert(0, REF)
+os.chdir("/tmp")
+from internal import math as rmath, stepfun as rstep, render as rrender, coord as rcoord, models as rmodels  # noqa: E402
+from internal import lidar_utils as rlidar  # noqa: E402
+
+
+# ---------------------------------------------------------------------------- helpers
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def rnd(seed, stream, shape, lo=0.0, hi=1.0):
+    return torch.from_numpy(synth.uniform(seed, stream, shape, lo, hi))
+
+
+def build_ref_model(mc: nconfig.ModelConfig, sd_np):
+    """Reference class tree configured like `mc` (gin bindings applied by hand) + our weights."""
+    for cls, cfg in ((rmodels.NerfMLP, mc.nerf_mlp), (rmodels.PropMLP, mc.prop_mlp)):
+        for f in ("bottleneck_width", "net_depth_viewdirs", "net_width_viewdirs", "skip_layer_dir", "deg_view",
+                  "disable_density_normals", "disable_rgb", "grid_level_dim", "grid_base_resolution",
+                  "grid_disired_resolution", "grid_log2_hashmap_size", "class_num"):
+            setattr(cls, f, getattr(cfg, f))
+    c = mc.config
+    cfg_ns = types.SimpleNamespace(use_semantic=c.use_semantic, analytic_gradient=c.analytic_gradient,
+                                   use_intensity=c.use_intensity, no_sem_layer=c.no_sem_layer, zero_glo=True,
+                                   instance_obj=False, sem_detach=True, vis_num_rays=c.vis_num_rays,
+                                   hash_decay_mults=0, symmetrize=False)
+    model = rmodels.Model(config=cfg_ns, raydist_fn=mc.raydist_fn, opaque_background=mc.opaque_background,
+                          num_prop_samples=tuple(mc.num_prop_samples), num_nerf_samples=mc.num_nerf_samples,
+                          num_levels=mc.num_levels, prop_desired_grid_size=list(mc.prop_desired_grid_size))
+    ref_sd = model.state_dict()
+    new_sd = {}
+    for k, v in ref_sd.items():
+        if k.endswith(".idx"):
+            continue
+        assert k in sd_np, f"reference key {k} missing from synth_state_dict"
+        t = torch.from_numpy(np.ascontiguousarray(sd_np[k]))
+        assert tuple(t.shape) == tuple(v.shape), (k, t.shape, v.shape)
+        if v.dtype in (torch.int32, torch.int64):
+            assert torch.equal(t.to(v.dtype), v), f"layout mismatch for {k}"
+        new_sd[k] = t.to(v.dtype)
+    missing = set(sd_np) - set(ref_sd)
+    assert not missing, f"synth keys unknown to the reference: {missing}"
+    model.load_state_dict(new_sd, strict=False)
+    model.eval()
+    return model
+
+
+# ---------------------------------------------------------------------------- per-function fixtures
+def gen_stepfun():
+    print("stepfun / math fixtures")
+    for seed, (N, S) in enumerate([(7, 64), (33, 32)]):
+        # monotone fenceposts in [0,1] with a few duplicated (zero-width) bins and weights incl. zeros
+        raw = rnd(seed, 1, (N, S + 1))
+        t = torch.sort(raw, dim=-1).values
+        t[:, 0] = 0.0
+        t[:, -1] = 1.0
+        t[::3, 5] = t[::3, 4]  # zero-width bin
+        w = rnd(seed, 2, (N, S)) ** 4
+        w[1::4, 7] = 0.0
+        w = w / w.sum(-1, keepdim=True)
+        for d in (0.0025 + 0.5 / 64, 0.0025 + 0.5 / 4096):
+            td, wd = rstep.max_dilate_weights(t, w, d, domain=(0., 1.), renormalize=True)
+            save(f"fn_max_dilate_s{seed}_d{int(d * 1e6)}", t=t, w=w, dilation=np.float32(d), t_dilate=td, w_dilate=wd)
+        logits = torch.where(t[..., 1:] > t[..., :-1], torch.log(w), torch.full_like(w, -torch.inf))
+        for ns in (32, 64, 128):
+            sd = rstep.sample_intervals(False, t, logits, ns, single_jitter=True, domain=(0., 1.))
+            save(f"fn_sample_intervals_s{seed}_n{ns}", t=t, logits=logits, sdist=sd)
+        # level-0 case: single interval [0,1], weight 1
+        t0 = torch.tensor([[0., 1.]]).repeat(N, 1)
+        sd0 = rstep.sample_intervals(False, t0, torch.zeros(N, 1), 64, single_jitter=True, domain=(0., 1.))
+        save(f"fn_sample_intervals_level0_s{seed}", t=t0, logits=torch.zeros(N, 1), sdist=sd0)
+        x = rnd(seed, 3, (N, 11))
+        xs = torch.sort(rnd(seed, 4, (N, S + 1)), dim=-1).values
+        fs = torch.sort(rnd(seed, 5, (N, S + 1)), dim=-1).values
+        save(f"fn_sorted_interp_s{seed}", x=x, xp=xs, fp=fs, out=rmath.sorted_interp(x, xs, fs))
+        wp = rnd(seed, 6, (N, S)) ** 2
+        wp = wp / wp.sum(-1, keepdim=True)
+        save(f"fn_weighted_percentile_s{seed}", t=t, w=wp, out=rstep.weighted_percentile(t, wp, [5, 50, 95]))
+
+
+def gen_coord_render():
+    print("coord / render fixtures")
+    for seed, (N, S) in enumerate([(7, 64), (19, 32)]):
+        near = torch.full((N, 1), 0.008)
+        far = torch.full((N, 1), 2.0)
+        _, s_to_t = rcoord.construct_ray_warps('power_transformation', near, far, -1.5)
+        s = torch.sort(rnd(seed, 10, (N, S + 1)), dim=-1).values
+        s[:, 0] = 0.0
+        s[:, -1] = 1.0
+        tdist = s_to_t(s)
+        save(f"fn_ray_warp_s{seed}", near=near, far=far, s=s, t=tdist)
+        o = rnd(seed, 11, (N, 3), -0.01, 0.01)
+        d = rnd(seed, 12, (N, 3), -1, 1)
+        d = d / d.norm(dim=-1, keepdim=True)
+        radii = torch.full((N, 1), 5e-4)
+        # LiDAR quirk (base = directions) and a camera-like orthonormal basis
+        bx = torch.linalg.cross(d, rnd(seed, 13, (N, 3), -1, 1))
+        bx = bx / bx.norm(dim=-1, keepdim=True)
+        by = torch.linalg.cross(d, bx)
+        for tag, (b0, b1, r) in {"lidar": (d, d, radii), "camera": (bx, by, radii * 4)}.items():
+            means, stds = rrender.cast_rays(tdist, o, d, r, False, n=7, m=3, std_scale=0.35,
+                                            batch=dict(base_x=b0, base_y=b1))
+            save(f"fn_cast_rays_{tag}_s{seed}", tdist=tdist, origins=o, directions=d, radii=r, base_x=b0,
+                 base_y=b1, means=means, stds=stds)
+        pts = rnd(seed, 14, (N * 5, 3), -3, 3)
+        pts[::7] *= 0.1
+        st = rnd(seed, 15, (N * 5,), 1e-5, 1e-2)
+        zm, zs = rcoord.track_linearize('contract', pts, st)
+        save(f"fn_contract_s{seed}", x=pts, std=st, z=zm, zstd=zs)
+        v = rnd(seed, 16, (N, 3), -1, 1)
+        save(f"fn_pos_enc_s{seed}", x=v, out=rcoord.pos_enc(v, 0, 4, append_identity=True))
+        dens = rnd(seed, 17, (N, S), 0, 30) ** 2 / 30
+        wts = rrender.compute_alpha_weights(dens, tdist, d * 1.7, opaque_background=True)[0]
+        wts_t = rrender.compute_alpha_weights(dens, tdist, d * 1.7, opaque_background=False)[0]
+        rgbs = rnd(seed, 18, (N, S, 3))
+        sem = torch.softmax(rnd(seed, 19, (N, S, 19), -2, 2), -1)
+        inten = rnd(seed, 20, (N, S, 1))
+        for tag, ww in (("opaque", wts), ("transparent", wts_t)):
+            r = rrender.volumetric_rendering(rgbs, ww, tdist, 1.0, far, True, semantic=sem, intensity=inten,
+                                             extras={}, sem_detach=True)
+            save(f"fn_composite_{tag}_s{seed}", density=dens, tdist=tdist, dirs=d * 1.7, rgbs=rgbs, sem=sem,
+                 intensity=inten, far=far, weights=ww, **{"out_" + k: v for k, v in r.items()})
+
+
+def gen_lidar():
+    print("lidar batch fixture")
+    az = np.linspace(270, -90, 40) / 180 * np.pi
+    d = rlidar.get_directions(nlidar.LIDAR_ANGLES[:5], az)
+    o = np.broadcast_to(np.array([[0.1, -0.2, 0.05]]), d.shape)
+    bs = lambda x: np.broadcast_to(x, (d.shape[0], 1))
+    b = rlidar.cast_lidar_ray_batch(o, d, dict(near=bs(0.008), far=bs(2.0), lossmult=bs(1.), cam_idx=bs(-1)))
+    save("fn_lidar_batch", az=az, beams=np.array(nlidar.LIDAR_ANGLES[:5]), origin=np.array([0.1, -0.2, 0.05]),
+         **{"out_" + k: np.asarray(v, np.float32) for k, v in b.items() if v is not None})
+
+
+# ---------------------------------------------------------------------------- MLP + whole forward
+def gen_mlp_and_forward():
+    cases = [
+        # name, workload, log2_hashmap, N, sweep width, seed, table_std
+        ("REF_small", "REF", 15, 96, 24, 0, 0.1),
+        ("C1_small", "C1", 15, 96, 24, 1, 0.1),
+        ("C2_small", "C2", 15, 64, 16, 0, 0.1),
+        ("REF_full", "REF", None, 64, 16, 1, 0.1),
+        ("REF_init", "REF", 15, 64, 16, 0, 1e-4),
+    ]
+    for name, wl, lg, N, width, seed, tstd in cases:
+        print(f"whole-forward fixture {name}")
+        mc = nconfig.workload(wl, lg)
+        sd_np = nweights.synth_state_dict(mc, seed=seed, table_std=tstd)
+        model = build_ref_model(mc, sd_np)
+        beams = nlidar.LIDAR_ANGLES[:: max(1, 32 // (N // width))][: N // width]
+        batch_np = nlidar.synthetic_sweep(width=width, seed=seed, beams=beams)
+        batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+        with torch.no_grad():
+            rend, hist = model(False, batch, train_frac=1.0, compute_extras=True, zero_glo=True)
+        out = {}
+        for k, v in rend[-1].items():
+            if not k.startswith("ray_"):
+                out["out_" + k] = v
+        K = 24  # per-sample history for the first K rays only (fixture size)
+        for lvl, h in enumerate(hist):
+            for k in ("sdist", "weights", "tdist", "density", "rgb", "semantic", "intensity"):
+                if h.get(k) is not None and not (k == "rgb" and lvl < len(hist) - 1):
+                    out[f"hist{lvl}_{k}"] = h[k][:K]
+            out[f"lvl{lvl}_depth"] = rend[lvl]["depth"]
+        save(f"fwd_{name}", workload=np.array(wl), log2_hashmap=np.array(-1 if lg is None else lg),
+             seed=np.array(seed), table_std=np.array(tstd, np.float64), width=np.array(width),
+             beams=np.array(beams), **{"in_" + k: v for k, v in batch_np.items()
+                                       if k in ("origins", "directions", "viewdirs", "radii", "near", "far")},
+             **out)
+        if name in ("REF_small", "C2_small"):
+            # MLP-level fixture (rows a-6..a-12): reference MLP.forward on the final level's gaussians
+            with torch.no_grad():
+                KM = 4
+                tdist = hist[-1]["tdist"][:KM]
+                means, stds = rrender.cast_rays(tdist, batch["origins"][:KM], batch["directions"][:KM],
+                                                batch["radii"][:KM], False, n=7, m=3, std_scale=0.35,
+                                                batch=dict(base_x=batch["base_x"][:KM], base_y=batch["base_y"][:KM]))
+                res = model.nerf_mlp(False, means, stds, viewdirs=batch["viewdirs"][:KM])
+                pres = model.prop_mlp_0(False, means, stds, viewdirs=batch["viewdirs"][:KM])
+                feats = model.nerf_mlp.encoder(rcoord.track_linearize('contract', means, stds)[0] / 2, bound=1)
+            save(f"mlp_{name}", workload=np.array(wl), log2_hashmap=np.array(lg), seed=np.array(seed),
+                 table_std=np.array(tstd, np.float64), means=means, stds=stds, viewdirs=batch["viewdirs"][:KM],
+                 enc_raw=feats, density=res["density"], rgb=res["rgb"], semantic=res["semantic"],
+                 **({"intensity": res["intensity"]} if res["intensity"] is not None else {}),
+                 prop_density=pres["density"])
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gen_stepfun()
+    gen_coord_render()
+    gen_lidar()
+    gen_mlp_and_forward()
+    print("done")
