@@ -67,13 +67,19 @@ def mlp_names(mc: ModelConfig) -> List[Tuple[str, MLPConfig]]:
 
 
 def synth_state_dict(mc: ModelConfig, seed: int = 0, table_std: float = 1e-4,
-                     head_gain: float = 1.0) -> Dict[str, np.ndarray]:
+                     trained_like: bool = False) -> Dict[str, np.ndarray]:
     """Seeded random-init parameters with the reference's init ranges.
 
-    table_std=1e-4 is the reference init (grid.py:101); SURVEY 8d's "trained-like" set uses 0.1
-    so that densities are non-degenerate.  head_gain scales density_layer.2 so that raw density
-    spans a useful range with random weights (1.0 = reference init).
+    table_std=1e-4 is the reference init (grid.py:101): with it every ray composites as uniform
+    fog, which exercises little.  trained_like=True is SURVEY 8d's second weight set: tables
+    U(-1,1) and a few heads rescaled so that the random scene has empty space, opaque surfaces
+    (density up to a few hundred), rays that reach the opaque background, and >10 distinct
+    semantic labels per sweep:
+      density_layer.2 (NerfMLP, all rows) x8, row 0 (raw density) x1500 in every MLP with its
+      bias shifted by -100, sem_layer.2.weight x8.
     """
+    if trained_like:
+        table_std = 1.0
     sd: Dict[str, np.ndarray] = {}
     for prefix, cfg in mlp_names(mc):
         offsets, sizes, _ = grid_layout(cfg)
@@ -83,8 +89,15 @@ def synth_state_dict(mc: ModelConfig, seed: int = 0, table_std: float = 1e-4,
         sd[f"{prefix}.encoder.grid_sizes"] = sizes
         for name, (o, i), kaiming in mlp_param_shapes(cfg):
             w, b = synth.linear_init(seed, f"{prefix}.{name}", o, i, kaiming)
-            if name == "density_layer.2" and head_gain != 1.0:
-                w = (w * np.float32(head_gain)).astype(np.float32)
-            sd[f"{prefix}.{name}.weight"] = w
-            sd[f"{prefix}.{name}.bias"] = b
+            if trained_like and name == "density_layer.2":
+                if not cfg.disable_rgb:
+                    w = w * np.float32(8.0)
+                    w[0] *= np.float32(1500.0 / 8.0)
+                else:
+                    w[0] *= np.float32(1500.0)
+                b[0] += np.float32(-100.0)
+            if trained_like and name == "sem_layer.2":
+                w = w * np.float32(8.0)
+            sd[f"{prefix}.{name}.weight"] = np.ascontiguousarray(w, np.float32)
+            sd[f"{prefix}.{name}.bias"] = np.ascontiguousarray(b, np.float32)
     return sd

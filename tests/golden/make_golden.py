@@ -251,17 +251,17 @@ def gen_lidar():
 # ---------------------------------------------------------------------------- MLP + whole forward
 def gen_mlp_and_forward():
     cases = [
-        # name, workload, log2_hashmap, N, sweep width, seed, table_std
-        ("REF_small", "REF", 15, 96, 24, 0, 0.1),
-        ("C1_small", "C1", 15, 96, 24, 1, 0.1),
-        ("C2_small", "C2", 15, 64, 16, 0, 0.1),
-        ("REF_full", "REF", None, 64, 16, 1, 0.1),
-        ("REF_init", "REF", 15, 64, 16, 0, 1e-4),
+        # name, workload, log2_hashmap, N, sweep width, seed, trained_like
+        ("REF_small", "REF", 15, 96, 24, 0, True),
+        ("C1_small", "C1", 15, 96, 24, 1, True),
+        ("C2_small", "C2", 15, 64, 16, 0, True),
+        ("REF_full", "REF", None, 64, 16, 1, True),
+        ("REF_init", "REF", 15, 64, 16, 0, False),
     ]
-    for name, wl, lg, N, width, seed, tstd in cases:
+    for name, wl, lg, N, width, seed, tl in cases:
         print(f"whole-forward fixture {name}")
         mc = nconfig.workload(wl, lg)
-        sd_np = nweights.synth_state_dict(mc, seed=seed, table_std=tstd)
+        sd_np = nweights.synth_state_dict(mc, seed=seed, trained_like=tl)
         model = build_ref_model(mc, sd_np)
         beams = nlidar.LIDAR_ANGLES[:: max(1, 32 // (N // width))][: N // width]
         batch_np = nlidar.synthetic_sweep(width=width, seed=seed, beams=beams)
@@ -279,7 +279,7 @@ def gen_mlp_and_forward():
                     out[f"hist{lvl}_{k}"] = h[k][:K]
             out[f"lvl{lvl}_depth"] = rend[lvl]["depth"]
         save(f"fwd_{name}", workload=np.array(wl), log2_hashmap=np.array(-1 if lg is None else lg),
-             seed=np.array(seed), table_std=np.array(tstd, np.float64), width=np.array(width),
+             seed=np.array(seed), trained_like=np.array(int(tl)), width=np.array(width),
              beams=np.array(beams), **{"in_" + k: v for k, v in batch_np.items()
                                        if k in ("origins", "directions", "viewdirs", "radii", "near", "far")},
              **out)
@@ -295,7 +295,7 @@ def gen_mlp_and_forward():
                 pres = model.prop_mlp_0(False, means, stds, viewdirs=batch["viewdirs"][:KM])
                 feats = model.nerf_mlp.encoder(rcoord.track_linearize('contract', means, stds)[0] / 2, bound=1)
             save(f"mlp_{name}", workload=np.array(wl), log2_hashmap=np.array(lg), seed=np.array(seed),
-                 table_std=np.array(tstd, np.float64), means=means, stds=stds, viewdirs=batch["viewdirs"][:KM],
+                 trained_like=np.array(int(tl)), means=means, stds=stds, viewdirs=batch["viewdirs"][:KM],
                  enc_raw=feats, density=res["density"], rgb=res["rgb"], semantic=res["semantic"],
                  **({"intensity": res["intensity"]} if res["intensity"] is not None else {}),
                  prop_density=pres["density"])

@@ -144,7 +144,7 @@ def test_grid_layout_full_size():
 def test_mlp_forward(name):
     g = golden(name)
     mc = nconfig.workload(str(g["workload"]), int(g["log2_hashmap"]))
-    sd = nweights.synth_state_dict(mc, seed=int(g["seed"]), table_std=float(g["table_std"]))
+    sd = nweights.synth_state_dict(mc, seed=int(g["seed"]), trained_like=bool(g["trained_like"]))
     enc = orc.make_encoders(sd, mc)
     sdt = orc.to_torch_sd(sd)
     res = orc.mlp_forward(sdt, "nerf_mlp", mc.nerf_mlp, enc["nerf_mlp"], T(g["means"]), T(g["stds"]), T(g["viewdirs"]))
@@ -162,7 +162,7 @@ def test_model_forward(name):
     g = golden(name)
     lg = int(g["log2_hashmap"])
     mc = nconfig.workload(str(g["workload"]), None if lg < 0 else lg)
-    sd = nweights.synth_state_dict(mc, seed=int(g["seed"]), table_std=float(g["table_std"]))
+    sd = nweights.synth_state_dict(mc, seed=int(g["seed"]), trained_like=bool(g["trained_like"]))
     batch_np = nlidar.synthetic_sweep(width=int(g["width"]), seed=int(g["seed"]), beams=list(g["beams"]))
     for k in ("origins", "directions", "viewdirs", "radii", "near", "far"):
         np.testing.assert_array_equal(batch_np[k], g["in_" + k])  # sweep generator is deterministic
