@@ -1,0 +1,224 @@
+/*
+ * nerflidar_hip.h -- C ABI of libnerflidar_hip.so (MI355X / gfx950 volume-render hot path).
+ *
+ * Drop-in boundary for fudan-zvg/NeRF-LiDAR's render path.  Citations are relative to
+ * NeRF_LiDAR/zipnerf/ in the reference (ZI = internal/).  Everything is `extern "C"`, plain
+ * pointers and sizes, no torch types.  Conventions:
+ *   - every function returns 0 (NLR_OK) or a negative NLR_ERR_* code; nlr_last_error() returns a
+ *     thread-local message (the reference raises via TORCH_CHECK, gridencoder.cu:15-18);
+ *   - all tensors are caller-owned and contiguous; "dev" = device (HBM) pointer, "host" = host
+ *     pointer; kernels never allocate (gridencoder/grid.py:47-50 does the same);
+ *   - `stream` is a hipStream_t passed as void* (NULL = legacy default stream).  The reference
+ *     always launches on stream 0 (gridencoder.cu:377); callers should pass PyTorch's current
+ *     stream;
+ *   - re-entrant, no global mutable state besides the thread-local error string.
+ */
+#ifndef NERFLIDAR_HIP_H
+#define NERFLIDAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLR_MAX_LEVELS 4      /* sampling levels (Model.num_levels, ZI/models.py:37) */
+#define NLR_MAX_GRID_LEVELS 16
+#define NLR_MAX_VIEW_DEPTH 16
+
+enum {
+    NLR_OK = 0,
+    NLR_ERR_INVALID = -1,     /* bad argument (shape, null pointer, alignment) */
+    NLR_ERR_UNSUPPORTED = -2, /* configuration outside the fused path (see message) */
+    NLR_ERR_HIP = -3,         /* a HIP runtime call or kernel launch failed */
+    NLR_ERR_WORKSPACE = -4    /* workspace too small: see nlr_workspace_bytes */
+};
+
+/* MLP arithmetic (NlrModelDesc.mlp_precision) */
+enum {
+    NLR_PREC_F32 = 0,   /* every layer on exact-f32 MFMA (v_mfma_f32_32x32x2_f32): reference-grade */
+    NLR_PREC_MIXED = 1, /* density/semantic/intensity layers f32 MFMA, view-MLP bf16 MFMA (default) */
+    NLR_PREC_FAST = 2   /* density/semantic/intensity layers split-bf16 (hi+lo, 3 MFMAs), view bf16 */
+};
+
+const char *nlr_last_error(void);
+int nlr_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * (1) Hash-grid operator.  Replaces the pybind entry points of gridencoder/src/bindings.cpp:5-7
+ *     (declared gridencoder/src/gridencoder.h:12-15).
+ *
+ * nlr_grid_encode_forward  <->  grid_encode_forward(inputs, embeddings, offsets, outputs,
+ *                                   B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp)
+ *   inputs      dev f32 [B, D]          points in [0,1]; anything outside -> zeros (cu:110-135)
+ *   embeddings  dev [sO, C]             table, f32 (table_dtype 0) or f16 (1; grid.py:43-44)
+ *   offsets     HOST i32 [L+1]          level offsets (grid.py:122-137).  The reference passes a
+ *                                       device tensor; the launcher needs the values on the host
+ *                                       (per-level scale/size go into kernel arguments), so the
+ *                                       Python shim keeps a CPU copy -- they never change.
+ *   outputs     dev f32: out_layout 0 = [L, B, C] (what the reference kernel writes, cu:388),
+ *                        out_layout 1 = [B, L*C] (what grid.py:57 permutes it into)
+ *   dy_dx       dev f32 [B, L*D*C] or NULL (cu:201-244)
+ *   D must be 3; C in {1,2,4,8}; L <= 16; S = log2(per_level_scale); H = base resolution.
+ * ------------------------------------------------------------------------------------------ */
+int nlr_grid_encode_forward(const float *inputs, const void *embeddings, int table_dtype,
+                            const int32_t *offsets_host, float *outputs, uint32_t B, uint32_t D,
+                            uint32_t C, uint32_t L, float S, uint32_t H, float *dy_dx,
+                            uint32_t gridtype, int align_corners, uint32_t interp, int out_layout,
+                            void *stream);
+
+/* nlr_grid_encode_backward <-> grid_encode_backward (gridencoder.h:13, cu:473-503).
+ *   grad [L,B,C] (grad_layout 0) or [B,L*C] (1); grad_embeddings dev f32 [sO,C] must be zeroed by
+ *   the caller (grid.py:77); float atomics -> summation order not reproducible, like the reference.
+ *   dy_dx / grad_inputs may be NULL together. */
+int nlr_grid_encode_backward(const float *grad, const float *inputs, const int32_t *offsets_host,
+                             float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                             float S, uint32_t H, const float *dy_dx, float *grad_inputs,
+                             uint32_t gridtype, int align_corners, uint32_t interp, int grad_layout,
+                             void *stream);
+
+/* Host helper shared with the CPU checker so both use bit-identical level constants
+ * (scale = exp2f(l*S)*H - 1, resolution = ceil(scale)+1; cu:138-139). */
+void nlr_level_scale(uint32_t L, float S, uint32_t H, float *scale, uint32_t *resolution);
+
+/* torch.linspace(start, end, n) in float32, as ZI/stepfun.py:203-216 uses it for the inverse-CDF
+ * sample positions u.  rand = 0: linspace(1/2n, 1 - 1/2n - eps, n); rand = 1: linspace(0, 1-u_max, n)
+ * and *max_jitter = (1-u_max)/(n-1) - eps.  Host only. */
+void nlr_sample_u(uint32_t n, int rand, float *u_host, float *max_jitter);
+
+/* ------------------------------------------------------------------------------------------
+ * (2) Model object: packed MLP weights (the only thing the library owns).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct NlrLinear {           /* torch.nn.Linear: y = x W^T + b */
+    const float *weight;             /* HOST f32 [out_features, in_features] (state_dict tensor) */
+    const float *bias;               /* HOST f32 [out_features] */
+    uint32_t out_features, in_features;
+} NlrLinear;
+
+typedef struct NlrGridDesc {         /* gridencoder.GridEncoder (grid.py:96-149) */
+    const void *table;               /* DEV  [sO, C]; not copied: training may update it in place */
+    int32_t table_dtype;             /* 0 = f32, 1 = f16 */
+    uint32_t num_levels, level_dim;  /* L, C */
+    uint32_t base_resolution;        /* H */
+    float log2_per_level_scale;      /* S */
+    const int32_t *offsets;          /* HOST i32 [L+1] (copied) */
+    uint32_t gridtype;               /* 0 hash, 1 tiled */
+    uint32_t align_corners;
+    uint32_t interp;                 /* 0 linear, 1 smoothstep */
+} NlrGridDesc;
+
+typedef struct NlrMlpDesc {          /* ZI/models.py:MLP (796-961) as configured at inference */
+    NlrGridDesc grid;
+    NlrLinear density0, density2;    /* density_layer.0 (L*C->64), density_layer.2 (64-> 1 | bottleneck) */
+    uint32_t disable_rgb;            /* PropMLP: density only (models.py:1119-1122) */
+    uint32_t bottleneck_width;       /* 256 */
+    uint32_t net_depth_viewdirs, net_width_viewdirs, skip_layer_dir, deg_view;
+    NlrLinear view[NLR_MAX_VIEW_DEPTH]; /* lin_second_stage_i (models.py:939-950) */
+    NlrLinear rgb_layer;
+    uint32_t use_semantic, no_sem_layer, class_num;
+    NlrLinear sem0, sem2;            /* sem_layer.0/.2 (models.py:955-957) */
+    uint32_t use_intensity;
+    NlrLinear int0, int2;            /* intensity_layer.0/.2 (models.py:959-961) */
+    float density_bias, rgb_premultiplier, rgb_bias, rgb_padding;
+    uint32_t re_weights;             /* erf down-weighting of fine levels (models.py:975-977) */
+} NlrMlpDesc;
+
+typedef struct NlrModelDesc {        /* ZI/models.py:Model (31-58) */
+    uint32_t num_levels;                         /* sampling levels; last one is the NerfMLP */
+    uint32_t num_samples[NLR_MAX_LEVELS];        /* num_prop_samples..., num_nerf_samples */
+    const NlrMlpDesc *mlps[NLR_MAX_LEVELS];      /* prop_mlp_0.., nerf_mlp */
+    float dilation_multiplier, dilation_bias;    /* 0.5, 0.0025 */
+    float anneal_slope, resample_padding;        /* 10, 0 */
+    float power_lambda, std_scale;               /* -1.5, 0.35 */
+    float bg_intensity;                          /* bg_intensity_range midpoint (1.0) */
+    uint32_t opaque_background;
+    uint32_t mlp_precision;                      /* NLR_PREC_* */
+} NlrModelDesc;
+
+typedef struct NlrModel NlrModel;
+int nlr_model_create(const NlrModelDesc *desc, NlrModel **out, void *stream);
+void nlr_model_destroy(NlrModel *m);
+/* Re-point a level's hash table (e.g. after an optimizer step re-allocated the parameter). */
+int nlr_model_set_table(NlrModel *m, uint32_t level, const void *table_dev, int table_dtype);
+
+/* ------------------------------------------------------------------------------------------
+ * (3) Fused render op.  Replaces Model.forward (ZI/models.py:239-576) for instance_obj=False,
+ *     num_glo_features=0:  per level  max_dilate_weights -> sample_intervals -> s_to_t ->
+ *     cast_rays -> MLP -> compute_alpha_weights -> volumetric_rendering.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct NlrRays {             /* the batch dict of ZI/lidar_utils.py:8-33 / camera_utils.py:567-617 */
+    const float *origins, *directions, *viewdirs;   /* dev f32 [N,3] */
+    const float *radii, *near, *far;                /* dev f32 [N,1] */
+    const float *base_x, *base_y;                   /* dev f32 [N,3] (LiDAR: both = directions) */
+} NlrRays;
+
+typedef struct NlrRenderCfg {
+    float train_frac;                /* 1.0 at render time (models.py:343-346 anneal) */
+    uint32_t compute_extras;         /* acc, distance_mean, percentiles (render.py:255-282) */
+    uint32_t sample_n, sample_m;     /* 7, 3 multisamples / loops (configs.py:143-148) */
+    /* rand=True support: per-level uniform [0,1) draws replacing torch.rand; NULL = deterministic.
+       jitter [N] (stepfun.py:216, single_jitter), deg [N, S_l, sample_n] (render.py:150). */
+    const float *rand_jitter[NLR_MAX_LEVELS];
+    const float *rand_deg[NLR_MAX_LEVELS];
+    float scale_factor;              /* >0: also emit points/labels (render_lidar.py:142-161) */
+} NlrRenderCfg;
+
+typedef struct NlrLevelOut {         /* one ray_history entry (models.py:553-557); any may be NULL */
+    float *sdist, *tdist;            /* [N, S+1] */
+    float *weights, *density;        /* [N, S] */
+    float *rgb;                      /* [N, S, 3]  (final level) */
+    float *semantic;                 /* [N, S, class_num] probabilities (final level) */
+    float *intensity;                /* [N, S] (final level) */
+    float *depth;                    /* [N] per-level rendering['depth'] */
+} NlrLevelOut;
+
+typedef struct NlrOut {              /* renderings[-1] (render.py:219-284); any may be NULL */
+    float *rgb;                      /* [N,3] */
+    float *depth;                    /* [N]   */
+    float *semantic;                 /* [N,class_num] */
+    float *intensity;                /* [N]   */
+    float *acc, *distance_mean, *distance_median, *distance_percentile_5, *distance_percentile_95; /* [N] */
+    int32_t *labels;                 /* [N] argmax_c semantic (render_lidar.py:158-159) */
+    float *points;                   /* [N,3] (o + depth*d)/scale_factor (render_lidar.py:142-156) */
+    NlrLevelOut history[NLR_MAX_LEVELS];
+} NlrOut;
+
+size_t nlr_workspace_bytes(const NlrModel *m, uint32_t N);
+int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t N, const NlrRenderCfg *cfg,
+                    const NlrOut *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Name + average duration bookkeeping is left to rocprofv3; these return the kernel names the
+ * library launches so bench.py can match the trace rows.  Host only. */
+const char *nlr_kernel_names(void);
+
+/* ------------------------------------------------------------------------------------------
+ * (4) Stage entry points: the same kernels nlr_render_rays chains, exposed one by one so each
+ *     row of the scope table can be parity-checked in isolation.
+ * ------------------------------------------------------------------------------------------ */
+/* a-3 + a-4 + a-2: resample one level.  prev_* NULL/n_prev = 0 means the initial [0,1] interval
+ * (models.py:296-300).  dilation <= 0 skips max_dilate_weights (level 0, models.py:332). */
+int nlr_resample_level(const float *prev_sdist, const float *prev_weights, uint32_t n_prev,
+                       float dilation, float anneal, float resample_padding, uint32_t num_samples,
+                       const float *rand_jitter, const float *near, const float *far,
+                       float power_lambda, uint32_t N, float *sdist, float *tdist, void *stream);
+
+/* a-5..a-12: cast + contract + encode + MLP for level `level` of the model.  tdist [N,S+1]. */
+int nlr_mlp_level(const NlrModel *m, uint32_t level, const NlrRays *rays, const float *tdist,
+                  uint32_t N, uint32_t sample_n, uint32_t sample_m, const float *rand_deg,
+                  float *features /* [N*S, L*C] or NULL */, float *density, float *rgb,
+                  float *semantic, float *intensity, void *workspace, size_t workspace_bytes,
+                  void *stream);
+
+/* a-13 + a-14 (+ a-16 post-step when labels/points are given). */
+int nlr_composite_level(const float *density, const float *tdist, const float *directions,
+                        const float *rgb, const float *semantic, const float *intensity,
+                        const float *far, const float *origins, uint32_t N, uint32_t S,
+                        uint32_t class_num, int opaque_background, float bg, int compute_extras,
+                        float scale_factor, float *weights, const NlrOut *out, float *level_depth,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFLIDAR_HIP_H */

@@ -1,0 +1,515 @@
+// Host side of libnerflidar_hip.so: error plumbing, model object (weight packing), workspace carving and
+// the level loop of Model.forward (ZI/models.py:316-557) as a chain of kernel launches on one stream.
+#include <stdarg.h>
+
+#include <vector>
+
+#include "nlr_kernels.h"
+
+
+static thread_local char g_err[512] = "";
+void nlr_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *nlr_last_error(void) { return g_err; }
+extern "C" int nlr_version(void) { return 100; }
+extern "C" const char *nlr_kernel_names(void) {
+    return "nlr_resample_kernel,nlr_prop_kernel,nlr_encode_kernel,nlr_dirbias_kernel,nlr_mlp_kernel,nlr_composite_kernel,"
+           "nlr_grid_fwd_kernel,nlr_grid_bwd_kernel,nlr_grid_input_bwd_kernel";
+}
+
+// ---- model ------------------------------------------------------------------------------------------
+struct LevelModel {
+    bool is_prop = false;
+    GridParams gp;
+    uint32_t F = 0, S = 0;
+    int re_weights = 1;
+    float density_bias = -1.0f;
+    // proposal MLP (fp32 VALU)
+    float *p_w1 = nullptr, *p_b1 = nullptr, *p_w2 = nullptr;
+    float p_b2 = 0.0f;
+    // NerfMLP (matrix cores)
+    uint32_t W = 0, WB = 0, D = 0, HT = 0, K = 0, int_row = 0xffffffffu, deg = 0, E = 0;
+    bool use_int = false, view_f32 = false;
+    float rgb_premul = 1.0f, rgb_bias = 0.0f, rgb_padding = 0.001f;
+    void *w_d0 = nullptr, *w_d2 = nullptr, *w_h1 = nullptr, *w_h2 = nullptr;
+    float *b_d0 = nullptr, *b_d2 = nullptr, *b_h1 = nullptr, *b_h2 = nullptr;
+    void *w_v0 = nullptr, *w_v1a = nullptr, *w_v1b = nullptr, *w_vl = nullptr, *w_rgb = nullptr;
+    float *b_vl = nullptr, *b_rgb = nullptr;
+    size_t vl_stride = 0;
+    float *wd0 = nullptr, *wd1 = nullptr, *b0 = nullptr, *b1 = nullptr;  // dir-encoding columns + biases of layers 0/1
+    float *u_det = nullptr, *u_rand = nullptr;                            // sample positions [S]
+    float max_jitter = 0.0f;
+};
+
+struct NlrModel {
+    uint32_t num_levels = 0;
+    LevelModel lv[NLR_MAX_LEVELS];
+    float dilation_multiplier, dilation_bias, anneal_slope, resample_padding, power_lambda, std_scale, bg;
+    uint32_t opaque, prec;
+    std::vector<void *> allocs;
+};
+
+static int dev_upload(NlrModel *m, const void *host, size_t bytes, void **out) {
+    void *p = nullptr;
+    NLR_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    m->allocs.push_back(p);
+    if (bytes) NLR_HIP(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+    *out = p;
+    return NLR_OK;
+}
+
+static uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x007fffffu)) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                                // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+// Dense row-major matrix view used while fusing / slicing the reference's Linear layers.
+struct Mat {
+    std::vector<float> a;
+    uint32_t rows = 0, cols = 0;
+    Mat() {}
+    Mat(uint32_t r, uint32_t c) : a((size_t)r * c, 0.0f), rows(r), cols(c) {}
+    float &at(uint32_t r, uint32_t c) { return a[(size_t)r * cols + c]; }
+    float get(uint32_t r, uint32_t c) const { return (r < rows && c < cols) ? a[(size_t)r * cols + c] : 0.0f; }
+};
+
+static Mat mat_from(const NlrLinear &l, uint32_t col0, uint32_t ncols) {
+    Mat m(l.out_features, ncols);
+    for (uint32_t r = 0; r < l.out_features; ++r)
+        for (uint32_t c = 0; c < ncols; ++c) m.at(r, c) = l.weight[(size_t)r * l.in_features + col0 + c];
+    return m;
+}
+
+// f32 fragments: [kgroup][otile][lane] float4; lane (i = lane&31, h = lane>>5), element e:
+//   row = 32*o + i, input feature = 8*g + 4*h + e    (k-step s = 4*(g&3)+e of input tile g>>2 reads accumulator
+//   register s, whose feature row for lane half h is (s&3) + 8*(s>>2) + 4*h = e + 8*(g&3) + 4*h)
+static std::vector<float> pack_f32(const Mat &w, uint32_t OT, uint32_t KG) {
+    std::vector<float> p((size_t)KG * OT * 64 * 4);
+    for (uint32_t g = 0; g < KG; ++g)
+        for (uint32_t o = 0; o < OT; ++o)
+            for (uint32_t lane = 0; lane < 64; ++lane)
+                for (uint32_t e = 0; e < 4; ++e)
+                    p[(((size_t)g * OT + o) * 64 + lane) * 4 + e] = w.get(32 * o + (lane & 31), 8 * g + 4 * (lane >> 5) + e);
+    return p;
+}
+
+// bf16 fragments: [kstep][otile][lane] 8 x bf16; element j of lane half h is input feature
+//   16*g + 8*(j>>2) + 4*h + (j&3)   (the k order of an accumulator tile reused as B operand)
+static std::vector<uint16_t> pack_bf16(const Mat &w, uint32_t OT, uint32_t KG) {
+    std::vector<uint16_t> p((size_t)KG * OT * 64 * 8);
+    for (uint32_t g = 0; g < KG; ++g)
+        for (uint32_t o = 0; o < OT; ++o)
+            for (uint32_t lane = 0; lane < 64; ++lane)
+                for (uint32_t j = 0; j < 8; ++j)
+                    p[(((size_t)g * OT + o) * 64 + lane) * 8 + j] =
+                        f32_to_bf16(w.get(32 * o + (lane & 31), 16 * g + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)));
+    return p;
+}
+
+static int upload_packed(NlrModel *m, const Mat &w, uint32_t out_pad, uint32_t in_pad, bool f32, void **out, size_t *elems16 = nullptr) {
+    const uint32_t OT = out_pad / 32;
+    if (f32) {
+        auto p = pack_f32(w, OT, in_pad / 8);
+        if (elems16) *elems16 = p.size() / 4;
+        return dev_upload(m, p.data(), p.size() * sizeof(float), out);
+    }
+    auto p = pack_bf16(w, OT, in_pad / 16);
+    if (elems16) *elems16 = p.size() / 8;
+    return dev_upload(m, p.data(), p.size() * sizeof(uint16_t), out);
+}
+
+static int upload_bias(NlrModel *m, const float *b, uint32_t n, uint32_t pad, float **out) {
+    std::vector<float> v(pad, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) v[i] = b[i];
+    return dev_upload(m, v.data(), pad * sizeof(float), (void **)out);
+}
+
+static int check_linear(const NlrLinear &l, uint32_t out_f, uint32_t in_f, const char *name) {
+    NLR_CHECK_ARG(l.weight && l.bias, "%s: weight/bias is NULL", name);
+    NLR_CHECK_ARG(l.out_features == out_f && l.in_features == in_f, "%s: expected [%u,%u], got [%u,%u]", name, out_f, in_f,
+                  l.out_features, l.in_features);
+    return NLR_OK;
+}
+
+static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_t S, uint32_t prec) {
+    int rc = nlr_fill_grid_params(&lv.gp, d.grid.table, d.grid.table_dtype, d.grid.offsets, d.grid.num_levels,
+                                  d.grid.level_dim, d.grid.log2_per_level_scale, d.grid.base_resolution, d.grid.gridtype,
+                                  (int)d.grid.align_corners, d.grid.interp);
+    if (rc) return rc;
+    NLR_CHECK_ARG(d.grid.table != nullptr, "mlp: hash table pointer is NULL");
+    lv.S = S;
+    lv.F = d.grid.num_levels * d.grid.level_dim;
+    lv.re_weights = d.re_weights ? 1 : 0;
+    lv.density_bias = d.density_bias;
+    lv.is_prop = d.disable_rgb != 0;
+    // sample positions u (stepfun.py:203-216)
+    {
+        std::vector<float> u(S);
+        float mj = 0.0f;
+        nlr_sample_u(S, 0, u.data(), nullptr);
+        if ((rc = dev_upload(m, u.data(), S * sizeof(float), (void **)&lv.u_det))) return rc;
+        nlr_sample_u(S, 1, u.data(), &mj);
+        lv.max_jitter = mj;
+        if ((rc = dev_upload(m, u.data(), S * sizeof(float), (void **)&lv.u_rand))) return rc;
+    }
+    if ((rc = check_linear(d.density0, 64, lv.F, "density_layer.0"))) return rc;
+    if (lv.is_prop) {
+        if ((rc = check_linear(d.density2, 1, 64, "density_layer.2 (PropMLP)"))) return rc;
+        if ((rc = dev_upload(m, d.density0.weight, (size_t)64 * lv.F * 4, (void **)&lv.p_w1))) return rc;
+        if ((rc = dev_upload(m, d.density0.bias, 64 * 4, (void **)&lv.p_b1))) return rc;
+        if ((rc = dev_upload(m, d.density2.weight, 64 * 4, (void **)&lv.p_w2))) return rc;
+        lv.p_b2 = d.density2.bias[0];
+        return NLR_OK;
+    }
+    // ---- NerfMLP
+    lv.W = d.net_width_viewdirs;
+    lv.WB = d.bottleneck_width;
+    lv.D = d.net_depth_viewdirs;
+    lv.deg = d.deg_view;
+    lv.E = 3 + 6 * d.deg_view;
+    lv.rgb_premul = d.rgb_premultiplier;
+    lv.rgb_bias = d.rgb_bias;
+    lv.rgb_padding = d.rgb_padding;
+    lv.view_f32 = (prec == NLR_PREC_F32);
+    if (prec == NLR_PREC_FAST) NLR_FAIL(NLR_ERR_UNSUPPORTED, "NLR_PREC_FAST (split-bf16 heads) is not built yet");
+    if (lv.D < 2 || d.skip_layer_dir != 0 || lv.D > NLR_MAX_VIEW_DEPTH)
+        NLR_FAIL(NLR_ERR_UNSUPPORTED, "view MLP: fused path needs net_depth_viewdirs in [2,%d] and skip_layer_dir = 0 (got %u, %u)",
+                 NLR_MAX_VIEW_DEPTH, lv.D, d.skip_layer_dir);
+    if (lv.W % 32 || lv.WB % 32) NLR_FAIL(NLR_ERR_UNSUPPORTED, "view MLP: widths must be multiples of 32");
+    if (lv.F % 4) NLR_FAIL(NLR_ERR_UNSUPPORTED, "NerfMLP: L*C = %u must be a multiple of 4", lv.F);
+    if ((rc = check_linear(d.density2, lv.WB, 64, "density_layer.2"))) return rc;
+    const bool sem_layer = d.use_semantic && !d.no_sem_layer;
+    if (d.use_semantic && d.no_sem_layer)
+        NLR_FAIL(NLR_ERR_UNSUPPORTED, "use_semantic with no_sem_layer=True (semantic = bottleneck[1:1+K]) has no fused path yet");
+    lv.K = sem_layer ? d.class_num : 0;
+    lv.use_int = d.use_intensity != 0;
+    lv.HT = (sem_layer ? 2 : 0) + (lv.use_int ? 2 : 0);
+    NLR_CHECK_ARG(lv.K + (lv.use_int ? 1 : 0) <= 32, "class_num %u (+intensity) exceeds one 32-row output tile", lv.K);
+
+    const uint32_t Fpad = ((lv.F + 7) / 8) * 8;
+    // density trunk
+    if ((rc = upload_packed(m, mat_from(d.density0, 0, lv.F), 64, Fpad, true, &lv.w_d0))) return rc;
+    if ((rc = upload_bias(m, d.density0.bias, 64, 64, &lv.b_d0))) return rc;
+    if ((rc = upload_packed(m, mat_from(d.density2, 0, 64), lv.WB, 64, true, &lv.w_d2))) return rc;
+    if ((rc = upload_bias(m, d.density2.bias, lv.WB, lv.WB, &lv.b_d2))) return rc;
+    // heads: [sem0 ; int0] stacked, then a block-diagonal [sem2 | 0 ; 0 | int2] into one 32-row tile
+    if (lv.HT) {
+        const uint32_t HH = lv.HT * 32;
+        Mat h1(HH, lv.WB), h2(32, HH);
+        std::vector<float> b1(HH, 0.0f), b2(32, 0.0f);
+        uint32_t r0 = 0;
+        if (sem_layer) {
+            if ((rc = check_linear(d.sem0, 64, lv.WB, "sem_layer.0"))) return rc;
+            if ((rc = check_linear(d.sem2, d.class_num, 64, "sem_layer.2"))) return rc;
+            for (uint32_t r = 0; r < 64; ++r) {
+                for (uint32_t c = 0; c < lv.WB; ++c) h1.at(r0 + r, c) = d.sem0.weight[(size_t)r * lv.WB + c];
+                b1[r0 + r] = d.sem0.bias[r];
+            }
+            for (uint32_t r = 0; r < d.class_num; ++r) {
+                for (uint32_t c = 0; c < 64; ++c) h2.at(r, r0 + c) = d.sem2.weight[(size_t)r * 64 + c];
+                b2[r] = d.sem2.bias[r];
+            }
+            r0 += 64;
+        }
+        if (lv.use_int) {
+            if ((rc = check_linear(d.int0, 64, lv.WB, "intensity_layer.0"))) return rc;
+            if ((rc = check_linear(d.int2, 1, 64, "intensity_layer.2"))) return rc;
+            lv.int_row = lv.K;
+            for (uint32_t r = 0; r < 64; ++r) {
+                for (uint32_t c = 0; c < lv.WB; ++c) h1.at(r0 + r, c) = d.int0.weight[(size_t)r * lv.WB + c];
+                b1[r0 + r] = d.int0.bias[r];
+            }
+            for (uint32_t c = 0; c < 64; ++c) h2.at(lv.int_row, r0 + c) = d.int2.weight[c];
+            b2[lv.int_row] = d.int2.bias[0];
+        }
+        if ((rc = upload_packed(m, h1, HH, lv.WB, true, &lv.w_h1))) return rc;
+        if ((rc = upload_bias(m, b1.data(), HH, HH, &lv.b_h1))) return rc;
+        if ((rc = upload_packed(m, h2, 32, HH, true, &lv.w_h2))) return rc;
+        if ((rc = upload_bias(m, b2.data(), 32, 32, &lv.b_h2))) return rc;
+    }
+    // view MLP.  Input of layer 0 = [bottleneck (WB) | dir_enc (E)]; of layer 1 = [x (W) | bottleneck | dir_enc]
+    const uint32_t in0 = lv.WB + lv.E, in1 = lv.W + in0;
+    if ((rc = check_linear(d.view[0], lv.W, in0, "lin_second_stage_0"))) return rc;
+    if ((rc = check_linear(d.view[1], lv.W, in1, "lin_second_stage_1"))) return rc;
+    const bool vf = lv.view_f32;
+    if ((rc = upload_packed(m, mat_from(d.view[0], 0, lv.WB), lv.W, lv.WB, vf, &lv.w_v0))) return rc;
+    if ((rc = upload_packed(m, mat_from(d.view[1], 0, lv.W), lv.W, lv.W, vf, &lv.w_v1a))) return rc;
+    if ((rc = upload_packed(m, mat_from(d.view[1], lv.W, lv.WB), lv.W, lv.WB, vf, &lv.w_v1b))) return rc;
+    {
+        Mat e0 = mat_from(d.view[0], lv.WB, lv.E), e1 = mat_from(d.view[1], lv.W + lv.WB, lv.E);
+        if ((rc = dev_upload(m, e0.a.data(), e0.a.size() * 4, (void **)&lv.wd0))) return rc;
+        if ((rc = dev_upload(m, e1.a.data(), e1.a.size() * 4, (void **)&lv.wd1))) return rc;
+        if ((rc = dev_upload(m, d.view[0].bias, lv.W * 4, (void **)&lv.b0))) return rc;
+        if ((rc = dev_upload(m, d.view[1].bias, lv.W * 4, (void **)&lv.b1))) return rc;
+    }
+    if (lv.D > 2) {
+        std::vector<uint8_t> blob;
+        std::vector<float> bl((size_t)(lv.D - 2) * lv.W);
+        size_t per = 0;
+        for (uint32_t l = 2; l < lv.D; ++l) {
+            char nm[64];
+            snprintf(nm, sizeof(nm), "lin_second_stage_%u", l);
+            if ((rc = check_linear(d.view[l], lv.W, lv.W, nm))) return rc;
+            Mat wl = mat_from(d.view[l], 0, lv.W);
+            if (vf) {
+                auto p = pack_f32(wl, lv.W / 32, lv.W / 8);
+                per = p.size() / 4;
+                blob.insert(blob.end(), (uint8_t *)p.data(), (uint8_t *)(p.data() + p.size()));
+            } else {
+                auto p = pack_bf16(wl, lv.W / 32, lv.W / 16);
+                per = p.size() / 8;
+                blob.insert(blob.end(), (uint8_t *)p.data(), (uint8_t *)(p.data() + p.size()));
+            }
+            memcpy(&bl[(size_t)(l - 2) * lv.W], d.view[l].bias, lv.W * 4);
+        }
+        lv.vl_stride = per;
+        if ((rc = dev_upload(m, blob.data(), blob.size(), &lv.w_vl))) return rc;
+        if ((rc = dev_upload(m, bl.data(), bl.size() * 4, (void **)&lv.b_vl))) return rc;
+    }
+    if ((rc = check_linear(d.rgb_layer, 3, lv.W, "rgb_layer"))) return rc;
+    if ((rc = upload_packed(m, mat_from(d.rgb_layer, 0, lv.W), 32, lv.W, vf, &lv.w_rgb))) return rc;
+    if ((rc = upload_bias(m, d.rgb_layer.bias, 3, 32, &lv.b_rgb))) return rc;
+    return NLR_OK;
+}
+
+extern "C" int nlr_model_create(const NlrModelDesc *desc, NlrModel **out, void *stream) {
+    (void)stream;
+    NLR_CHECK_ARG(desc && out, "model_create: NULL argument");
+    NLR_CHECK_ARG(desc->num_levels >= 1 && desc->num_levels <= NLR_MAX_LEVELS, "num_levels %u outside [1,%d]", desc->num_levels,
+                  NLR_MAX_LEVELS);
+    NLR_CHECK_ARG(desc->mlp_precision <= NLR_PREC_FAST, "unknown mlp_precision %u", desc->mlp_precision);
+    NlrModel *m = new NlrModel();
+    m->num_levels = desc->num_levels;
+    m->dilation_multiplier = desc->dilation_multiplier;
+    m->dilation_bias = desc->dilation_bias;
+    m->anneal_slope = desc->anneal_slope;
+    m->resample_padding = desc->resample_padding;
+    m->power_lambda = desc->power_lambda;
+    m->std_scale = desc->std_scale;
+    m->bg = desc->bg_intensity;
+    m->opaque = desc->opaque_background;
+    m->prec = desc->mlp_precision;
+    for (uint32_t l = 0; l < desc->num_levels; ++l) {
+        int rc = NLR_OK;
+        if (!desc->mlps[l]) {
+            nlr_set_error("model_create: mlps[%u] is NULL", l);
+            rc = NLR_ERR_INVALID;
+        } else if (desc->num_samples[l] < 2 || desc->num_samples[l] > 512) {
+            nlr_set_error("num_samples must be in [2,512], is %u", desc->num_samples[l]);
+            rc = NLR_ERR_INVALID;
+        } else {
+            rc = build_level(m, m->lv[l], *desc->mlps[l], desc->num_samples[l], desc->mlp_precision);
+            const bool last = (l + 1 == desc->num_levels);
+            if (!rc && last && m->lv[l].is_prop) {
+                nlr_set_error("the last level must be a NerfMLP (disable_rgb = 0)");
+                rc = NLR_ERR_INVALID;
+            }
+            if (!rc && !last && !m->lv[l].is_prop) {
+                nlr_set_error("single_mlp / NerfMLP as proposal network has no fused path (level %u)", l);
+                rc = NLR_ERR_UNSUPPORTED;
+            }
+        }
+        if (rc) {
+            nlr_model_destroy(m);
+            return rc;
+        }
+    }
+    *out = m;
+    return NLR_OK;
+}
+
+extern "C" void nlr_model_destroy(NlrModel *m) {
+    if (!m) return;
+    for (void *p : m->allocs) hipFree(p);
+    delete m;
+}
+
+extern "C" int nlr_model_set_table(NlrModel *m, uint32_t level, const void *table_dev, int table_dtype) {
+    NLR_CHECK_ARG(m && level < m->num_levels && table_dev, "model_set_table: bad argument");
+    NLR_CHECK_ARG(table_dtype == 0 || table_dtype == 1, "model_set_table: table_dtype must be 0 or 1");
+    m->lv[level].gp.table = table_dev;
+    m->lv[level].gp.table_dtype = table_dtype;
+    return NLR_OK;
+}
+
+// ---- workspace ------------------------------------------------------------------------------------
+static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct Carve {
+    char *base;
+    size_t off = 0, cap;
+    Carve(void *p, size_t c) : base((char *)p), cap(c) {}
+    float *take(size_t nfloat) {
+        size_t b = al(nfloat * sizeof(float));
+        float *r = base ? (float *)(base + off) : nullptr;
+        off += b;
+        return r;
+    }
+};
+
+static size_t level_ws(const LevelModel &lv, uint32_t N, bool last) {
+    size_t S = lv.S, b = 0;
+    b += 2 * al((size_t)N * (S + 1) * 4);  // sdist, tdist
+    b += 2 * al((size_t)N * S * 4);        // weights, density
+    if (!lv.is_prop) {
+        b += al((size_t)N * S * lv.F * 4);               // features
+        b += al((size_t)N * S * 3 * 4);                  // rgb
+        b += al((size_t)N * S * (lv.K ? lv.K : 1) * 4);  // semantic
+        b += al((size_t)N * S * 4);                      // intensity
+        b += al((size_t)N * 2 * lv.W * 4);               // per-ray bias
+    }
+    (void)last;
+    return b;
+}
+
+extern "C" size_t nlr_workspace_bytes(const NlrModel *m, uint32_t N) {
+    if (!m) return 0;
+    size_t b = 256;
+    for (uint32_t l = 0; l < m->num_levels; ++l) b += level_ws(m->lv[l], N, l + 1 == m->num_levels);
+    return b;
+}
+
+// Run encode + MLP of one NerfMLP level (or the fused proposal kernel) for given tdist.
+static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays *rays, const float *tdist, uint32_t N,
+                         uint32_t n, uint32_t mloops, const float *rand_deg, float *feat, float *raybias, float *density,
+                         float *rgb, float *sem, float *inten, float *prop_feat, hipStream_t st) {
+    CastParams cp;
+    int rc = nlr_fill_cast_params(&cp, rays, tdist, rand_deg, N, lv.S, n, mloops, m->std_scale);
+    if (rc) return rc;
+    if (lv.is_prop) return nlr_launch_prop(cp, lv.gp, lv.p_w1, lv.p_b1, lv.p_w2, lv.p_b2, lv.density_bias, lv.re_weights, density, prop_feat, st);
+    if ((rc = nlr_launch_encode(cp, lv.gp, lv.re_weights, feat, st))) return rc;
+    if (rgb) {
+        NLR_CHECK_ARG(rays->viewdirs != nullptr, "NerfMLP: viewdirs is NULL");
+        DirBiasParams dp;
+        dp.viewdirs = rays->viewdirs;
+        dp.wd0 = lv.wd0;
+        dp.wd1 = lv.wd1;
+        dp.b0 = lv.b0;
+        dp.b1 = lv.b1;
+        dp.N = N;
+        dp.W = lv.W;
+        dp.deg = lv.deg;
+        dp.E = lv.E;
+        dp.out = raybias;
+        if ((rc = nlr_launch_dirbias(dp, st))) return rc;
+    }
+    MlpParams P;
+    memset(&P, 0, sizeof(P));
+    P.feat = feat;
+    P.M = N * lv.S;
+    P.S = lv.S;
+    P.F = lv.F;
+    P.w_d0 = (const f32x4 *)lv.w_d0;
+    P.w_d2 = (const f32x4 *)lv.w_d2;
+    P.w_h1 = (const f32x4 *)lv.w_h1;
+    P.w_h2 = (const f32x4 *)lv.w_h2;
+    P.b_d0 = lv.b_d0;
+    P.b_d2 = lv.b_d2;
+    P.b_h1 = lv.b_h1;
+    P.b_h2 = lv.b_h2;
+    P.w_v0 = lv.w_v0;
+    P.w_v1a = lv.w_v1a;
+    P.w_v1b = lv.w_v1b;
+    P.w_vl = lv.w_vl;
+    P.w_rgb = lv.w_rgb;
+    P.b_vl = lv.b_vl;
+    P.b_rgb = lv.b_rgb;
+    P.raybias = raybias;
+    P.depth = lv.D;
+    P.vl_stride = lv.vl_stride;
+    P.K = sem ? lv.K : 0;
+    P.int_row = lv.int_row;
+    P.density_bias = lv.density_bias;
+    P.rgb_premul = lv.rgb_premul;
+    P.rgb_bias = lv.rgb_bias;
+    P.rgb_padding = lv.rgb_padding;
+    P.density = density;
+    P.rgb = rgb;
+    P.sem = sem;
+    P.inten = (lv.use_int && inten) ? inten : nullptr;
+    return nlr_launch_mlp(P, lv.W, lv.WB, lv.HT, lv.view_f32, st);
+}
+
+extern "C" int nlr_mlp_level(const NlrModel *m, uint32_t level, const NlrRays *rays, const float *tdist, uint32_t N,
+                             uint32_t sample_n, uint32_t sample_m, const float *rand_deg, float *features, float *density,
+                             float *rgb, float *semantic, float *intensity, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+    NLR_CHECK_ARG(m && level < m->num_levels && rays && tdist && density, "mlp_level: bad argument");
+    if (N == 0) return NLR_OK;
+    const LevelModel &lv = m->lv[level];
+    hipStream_t st = (hipStream_t)stream;
+    if (lv.is_prop)
+        return run_mlp_level(m, lv, rays, tdist, N, sample_n, sample_m, rand_deg, nullptr, nullptr, density, nullptr, nullptr,
+                             nullptr, features, st);
+    Carve c(workspace, workspace_bytes);
+    float *feat = features ? features : c.take((size_t)N * lv.S * lv.F);
+    float *rb = c.take((size_t)N * 2 * lv.W);
+    float *sem = semantic ? semantic : (lv.K ? c.take((size_t)N * lv.S * lv.K) : nullptr);
+    if (c.off > workspace_bytes || (!workspace && c.off))
+        NLR_FAIL(NLR_ERR_WORKSPACE, "mlp_level: workspace %zu B < needed %zu B", workspace_bytes, c.off);
+    return run_mlp_level(m, lv, rays, tdist, N, sample_n, sample_m, rand_deg, feat, rb, density, rgb, sem, intensity, nullptr, st);
+}
+
+// ---- Model.forward ----------------------------------------------------------------------------------
+extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t N, const NlrRenderCfg *cfg, const NlrOut *out,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    NLR_CHECK_ARG(m && rays && cfg && out, "render_rays: NULL argument");
+    NLR_CHECK_ARG(rays->origins && rays->directions && rays->near && rays->far && rays->radii, "render_rays: ray batch has NULL tensors");
+    if (N == 0) return NLR_OK;
+    const size_t need = nlr_workspace_bytes(m, N);
+    if (!workspace || workspace_bytes < need)
+        NLR_FAIL(NLR_ERR_WORKSPACE, "render_rays: workspace %zu B < nlr_workspace_bytes() = %zu B", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    Carve c(workspace, workspace_bytes);
+    const uint32_t n = cfg->sample_n ? cfg->sample_n : 7, mloops = cfg->sample_m ? cfg->sample_m : 3;
+
+    const float *prev_s = nullptr, *prev_w = nullptr;
+    uint32_t n_prev = 0;
+    double prod = 1.0;
+    for (uint32_t l = 0; l < m->num_levels; ++l) {
+        const LevelModel &lv = m->lv[l];
+        const bool last = (l + 1 == m->num_levels);
+        const uint32_t S = lv.S;
+        const NlrLevelOut &ho = out->history[l];
+        float *sdist = ho.sdist ? ho.sdist : c.take((size_t)N * (S + 1));
+        float *tdist = ho.tdist ? ho.tdist : c.take((size_t)N * (S + 1));
+        float *weights = ho.weights ? ho.weights : c.take((size_t)N * S);
+        float *density = ho.density ? ho.density : c.take((size_t)N * S);
+        // models.py:322-346
+        const bool use_dil = m->dilation_bias > 0 || m->dilation_multiplier > 0;
+        const float dilation = (l > 0 && use_dil) ? (float)(m->dilation_bias + m->dilation_multiplier * 1.0 / prod) : 0.0f;
+        prod *= (double)S;
+        const float tf = cfg->train_frac;
+        const float anneal = m->anneal_slope > 0 ? (float)(((double)m->anneal_slope * tf) / (((double)m->anneal_slope - 1.0) * tf + 1.0)) : 1.0f;
+        const float *jit = cfg->rand_jitter[l];
+        int rc = nlr_launch_resample(prev_s, prev_w, n_prev, dilation, anneal, m->resample_padding, S, jit ? lv.u_rand : lv.u_det,
+                                     jit, lv.max_jitter, rays->near, rays->far, m->power_lambda, N, sdist, tdist, st);
+        if (rc) return rc;
+        float *feat = nullptr, *rb = nullptr, *rgb = nullptr, *sem = nullptr, *inten = nullptr;
+        if (!lv.is_prop) {
+            feat = c.take((size_t)N * S * lv.F);
+            rb = c.take((size_t)N * 2 * lv.W);
+            rgb = ho.rgb ? ho.rgb : c.take((size_t)N * S * 3);
+            sem = lv.K ? (ho.semantic ? ho.semantic : c.take((size_t)N * S * lv.K)) : nullptr;
+            inten = lv.use_int ? (ho.intensity ? ho.intensity : c.take((size_t)N * S)) : nullptr;
+        }
+        rc = run_mlp_level(m, lv, rays, tdist, N, n, mloops, cfg->rand_deg[l], feat, rb, density, rgb, sem, inten, nullptr, st);
+        if (rc) return rc;
+        rc = nlr_composite_level(density, tdist, rays->directions, last ? rgb : nullptr, last ? sem : nullptr, last ? inten : nullptr,
+                                 rays->far, rays->origins, N, S, lv.K, (int)m->opaque, m->bg, last ? (int)cfg->compute_extras : 0,
+                                 last ? cfg->scale_factor : 0.0f, weights, last ? out : nullptr, ho.depth, st);
+        if (rc) return rc;
+        prev_s = sdist;
+        prev_w = weights;
+        n_prev = S;
+    }
+    if (c.off > workspace_bytes) NLR_FAIL(NLR_ERR_WORKSPACE, "render_rays: carved %zu B > workspace %zu B", c.off, workspace_bytes);
+    return NLR_OK;
+}

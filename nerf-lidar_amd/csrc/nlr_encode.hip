@@ -1,0 +1,293 @@
+// Multisample cone casting + scene contraction + hash-grid encoding + erf down-weighting, fused.
+//
+// Replaces, per sampling level (rows a-5..a-9 of the scope table):
+//   ZI/render.py:129-168     cast_rays            -> means[N,S,7,3], stds[N,S,7]     (never stored here)
+//   ZI/coord.py:51-63,67-100 contract_mean_std    (track_linearize('contract'))
+//   ZI/models.py:968-979     /bound, GridEncoder, erf re-weighting, mean over the 7 multisamples
+//   gridencoder.cu:87-199    kernel_grid          (8-corner trilinear gather per level)
+//   ZI/models.py:887-889,996-997,1116  PropMLP density_layer + softplus (proposal levels only)
+// The reference writes means/stds/[B,L*C] raw features to HBM between these steps (for 32x1024 rays
+// x 128 samples x 7 that is 29.4 M points x 40 floats = 4.7 GB per sweep); here only the
+// 7-sample mean [N*S, L*C] leaves the kernel (NerfMLP level) or only the density (proposal levels).
+#include "nlr_kernels.h"
+
+#include <hip/hip_fp16.h>
+
+
+struct Gauss {  // one contracted multisample, mapped to the unit cube
+    float x0, x1, x2, zs;
+};
+
+__device__ __forceinline__ Gauss nlr_cast_one(const CastParams &cp, uint32_t ray, uint32_t k, uint32_t j, float t0, float t1,
+                                              const float *o, const float *d, const float *bx, const float *by, float radius) {
+    // render.py:147-156
+    const float t = t0 + ((t1 - t0) * ((float)j + 0.5f)) / (float)cp.n;
+    float cd = cp.cosd[j], sd = cp.sind[j];
+    if (cp.rand_deg) {
+        const float u = cp.rand_deg[((size_t)ray * cp.S + k) * cp.n + j];
+        const float deg = cp.degj[j] + (u * 3.14159274101257324f) * 2.0f;
+        cd = cosf(deg);
+        sd = sinf(deg);
+    }
+    const float lx = ((radius * t) * cd) / 2.0f;
+    const float ly = ((radius * t) * sd) / 2.0f;
+    float m[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m[c] = fmaf(t, d[c], fmaf(ly, by[c], lx * bx[c])) + o[c];  // render.py:162-164
+    const float std = (cp.std_scale * radius) * t;
+    // coord.py:51-63
+    const float m2 = fmaxf((m[0] * m[0] + m[1] * m[1]) + m[2] * m[2], NLR_EPS);
+    float zs = std;
+    if (!(m2 <= 1.0f)) {
+        const float sq = sqrtf(m2);
+        const float sc = (2.0f * sq - 1.0f) / m2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m[c] = sc * m[c];
+        const float a = 2.0f / sq - 1.0f / m2;
+        const float det = (1.0f / m2) * (a * a);
+        zs = powf(det, 0.3333333432674408f) * std;
+    }
+    Gauss g;
+    // models.py:971-973 (bound = 2) then grid.py:162 ((x + 1) / 2)
+    g.x0 = (m[0] / 2.0f + 1.0f) / 2.0f;
+    g.x1 = (m[1] / 2.0f + 1.0f) / 2.0f;
+    g.x2 = (m[2] / 2.0f + 1.0f) / 2.0f;
+    g.zs = zs / 2.0f;
+    return g;
+}
+
+template <typename T>
+__device__ __forceinline__ float nlr_ld(const T *p);
+template <>
+__device__ __forceinline__ float nlr_ld<float>(const float *p) { return *p; }
+template <>
+__device__ __forceinline__ float nlr_ld<__half>(const __half *p) { return __half2float(*p); }
+
+// Trilinear interpolation of C channels at one level (gridencoder.cu:137-197); acc += w_erf * value.
+template <typename T, int C>
+__device__ __forceinline__ void nlr_level_accum(const GridParams &gp, uint32_t level, const Gauss &g, float werf, float (&acc)[C]) {
+    if ((g.x0 < 0 || g.x0 > 1) || (g.x1 < 0 || g.x1 > 1) || (g.x2 < 0 || g.x2 > 1)) return;  // zeros
+    const T *grid = (const T *)gp.table + (size_t)gp.offset[level] * C;
+    const uint32_t hsize = gp.hsize[level], res = gp.res[level];
+    const float scale = gp.scale[level];
+    const float half = gp.align_corners ? 0.0f : 0.5f;
+    float pos[3] = {fmaf(g.x0, scale, half), fmaf(g.x1, scale, half), fmaf(g.x2, scale, half)};
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+        if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+    }
+    uint32_t idx[8];
+    float w[8];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        float ww = 1.0f;
+        uint32_t pl[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if ((c8 >> d) & 1) {
+                ww *= pos[d];
+                pl[d] = pg[d] + 1;
+            } else {
+                ww *= 1 - pos[d];
+                pl[d] = pg[d];
+            }
+        }
+        w[c8] = ww;
+        idx[c8] = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pl[0], pl[1], pl[2]) * C;
+    }
+    float v[8][C];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8)
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c8][c] = nlr_ld<T>(grid + idx[c8] + c);
+    float r[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) r[c] = 0.0f;
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8)
+#pragma unroll
+        for (int c = 0; c < C; ++c) r[c] = fmaf(w[c8], v[c8][c], r[c]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] += r[c] * werf;
+}
+
+// models.py:976: erf(1 / clamp(sqrt(8 * std^2 * G^2), min=1e-10))
+__device__ __forceinline__ float nlr_erf_weight(float zs, float gsize) {
+    return erff(1.0f / fmaxf(sqrtf((8.0f * (zs * zs)) * (gsize * gsize)), 1e-10f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// NerfMLP level: one thread per (sample, grid level); blockIdx.y = level (level-major dispatch keeps
+// one level's table hot in L2 / Infinity Cache).  Writes feat[M, L*C] (row-major, f32).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ void __launch_bounds__(256) nlr_encode_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = cp.N * cp.S;
+    if (m >= M) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    float o[3], d[3], bx[3], by[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = cp.origins[(size_t)ray * 3 + c];
+        d[c] = cp.directions[(size_t)ray * 3 + c];
+        bx[c] = cp.base_x[(size_t)ray * 3 + c];
+        by[c] = cp.base_y[(size_t)ray * 3 + c];
+    }
+    const float radius = cp.radii[ray];
+    const float t0 = cp.tdist[(size_t)ray * (cp.S + 1) + k], t1 = cp.tdist[(size_t)ray * (cp.S + 1) + k + 1];
+    const float gsize = gp.gsize[level];
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    for (uint32_t j = 0; j < cp.n; ++j) {
+        const Gauss g = nlr_cast_one(cp, ray, k, j, t0, t1, o, d, bx, by, radius);
+        const float werf = re_weights ? nlr_erf_weight(g.zs, gsize) : 1.0f;
+        nlr_level_accum<T, C>(gp, level, g, werf, acc);
+    }
+    float *f = feat + (size_t)m * gp.L * C + level * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) f[c] = acc[c] / (float)cp.n;  // .mean(dim=-3), models.py:977
+}
+
+// ---------------------------------------------------------------------------------------------
+// Proposal level: one thread per sample does every grid level and the tiny density MLP
+// (L*C -> 64 -> 1, fp32 VALU with wave-uniform weights) and writes only density[M].
+// ---------------------------------------------------------------------------------------------
+struct PropMlpParams {
+    const float *w1, *b1;  // dev [64, F], [64]
+    const float *w2;       // dev [64]  (row 0 of density_layer.2)
+    float b2, density_bias;
+    uint32_t F;
+};
+
+template <typename T, int C, int LMAX>
+__global__ void __launch_bounds__(256) nlr_prop_kernel(CastParams cp, GridParams gp, PropMlpParams mp, int re_weights,
+                                                       float *__restrict__ density, float *__restrict__ feat_out) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = cp.N * cp.S;
+    if (m >= M) return;
+    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    float o[3], d[3], bx[3], by[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = cp.origins[(size_t)ray * 3 + c];
+        d[c] = cp.directions[(size_t)ray * 3 + c];
+        bx[c] = cp.base_x[(size_t)ray * 3 + c];
+        by[c] = cp.base_y[(size_t)ray * 3 + c];
+    }
+    const float radius = cp.radii[ray];
+    const float t0 = cp.tdist[(size_t)ray * (cp.S + 1) + k], t1 = cp.tdist[(size_t)ray * (cp.S + 1) + k + 1];
+    float feat[LMAX * C];
+#pragma unroll
+    for (int i = 0; i < LMAX * C; ++i) feat[i] = 0.0f;
+    for (uint32_t j = 0; j < cp.n; ++j) {
+        const Gauss g = nlr_cast_one(cp, ray, k, j, t0, t1, o, d, bx, by, radius);
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < (int)gp.L) {
+                const float werf = re_weights ? nlr_erf_weight(g.zs, gp.gsize[l]) : 1.0f;
+                float a[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) a[c] = 0.0f;
+                nlr_level_accum<T, C>(gp, l, g, werf, a);
+#pragma unroll
+                for (int c = 0; c < C; ++c) feat[l * C + c] += a[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LMAX * C; ++i) feat[i] = feat[i] / (float)cp.n;
+    if (feat_out)
+        for (uint32_t i = 0; i < mp.F; ++i) feat_out[(size_t)m * mp.F + i] = feat[i];
+    float raw = mp.b2;
+    for (int h = 0; h < 64; ++h) {
+        float a = mp.b1[h];
+#pragma unroll
+        for (int i = 0; i < LMAX * C; ++i)
+            if (i < (int)mp.F) a = fmaf(mp.w1[h * mp.F + i], feat[i], a);
+        raw = fmaf(mp.w2[h], fmaxf(a, 0.0f), raw);
+    }
+    const float x = raw + mp.density_bias;
+    density[m] = x > 20.0f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20), models.py:1116
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist, const float *rand_deg, uint32_t N,
+                         uint32_t S, uint32_t n, uint32_t mloops, float std_scale) {
+    NLR_CHECK_ARG(n >= 1 && n <= NLR_MAX_MULTI, "cast: sample_n=%u outside [1,%d]", n, NLR_MAX_MULTI);
+    NLR_CHECK_ARG(rays && rays->origins && rays->directions && rays->radii && rays->base_x && rays->base_y,
+                  "cast: ray batch has NULL origins/directions/radii/base_x/base_y");
+    memset(cp, 0, sizeof(*cp));
+    cp->origins = rays->origins;
+    cp->directions = rays->directions;
+    cp->base_x = rays->base_x;
+    cp->base_y = rays->base_y;
+    cp->radii = rays->radii;
+    cp->tdist = tdist;
+    cp->rand_deg = rand_deg;
+    cp->N = N;
+    cp->S = S;
+    cp->n = n;
+    cp->std_scale = std_scale;
+    for (uint32_t j = 0; j < n; ++j) {
+        // `2 * torch.pi * m * j / n` with j an int64 tensor: float32(2*pi*m) * float32(j), then / n
+        const float deg = ((float)(2.0 * M_PI * (double)mloops) * (float)j) / (float)n;
+        cp->degj[j] = deg;
+        cp->cosd[j] = cosf(deg);
+        cp->sind[j] = sinf(deg);
+    }
+    return NLR_OK;
+}
+
+int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, hipStream_t st) {
+    const uint32_t M = cp.N * cp.S;
+    dim3 grid((M + 255) / 256, gp.L), block(256);
+#define NLR_ENC(T, C) hipLaunchKernelGGL((nlr_encode_kernel<T, C>), grid, block, 0, st, cp, gp, re_weights, feat)
+    if (gp.table_dtype == 0) {
+        switch (gp.C) {
+            case 1: NLR_ENC(float, 1); break;
+            case 2: NLR_ENC(float, 2); break;
+            case 4: NLR_ENC(float, 4); break;
+            default: NLR_ENC(float, 8); break;
+        }
+    } else {
+        switch (gp.C) {
+            case 1: NLR_ENC(__half, 1); break;
+            case 2: NLR_ENC(__half, 2); break;
+            case 4: NLR_ENC(__half, 4); break;
+            default: NLR_ENC(__half, 8); break;
+        }
+    }
+#undef NLR_ENC
+    NLR_LAUNCH_CHECK("nlr_encode_kernel");
+    return NLR_OK;
+}
+
+int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1, const float *b1, const float *w2, float b2,
+                    float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st) {
+    const uint32_t M = cp.N * cp.S;
+    PropMlpParams mp;
+    mp.w1 = w1;
+    mp.b1 = b1;
+    mp.w2 = w2;
+    mp.b2 = b2;
+    mp.density_bias = density_bias;
+    mp.F = gp.L * gp.C;
+    NLR_CHECK_ARG(mp.F <= 16, "proposal MLP: L*C = %u > 16 features is outside the fused proposal kernel", mp.F);
+    dim3 grid((M + 255) / 256), block(256);
+#define NLR_PROP(T, C, LM) hipLaunchKernelGGL((nlr_prop_kernel<T, C, LM>), grid, block, 0, st, cp, gp, mp, re_weights, density, feat_out)
+    const bool f32 = gp.table_dtype == 0;
+    if (gp.C == 1 && gp.L <= 8) { if (f32) NLR_PROP(float, 1, 8); else NLR_PROP(__half, 1, 8); }
+    else if (gp.C == 1) { if (f32) NLR_PROP(float, 1, 16); else NLR_PROP(__half, 1, 16); }
+    else if (gp.C == 2) { if (f32) NLR_PROP(float, 2, 8); else NLR_PROP(__half, 2, 8); }
+    else if (gp.C == 4 && gp.L <= 4) { if (f32) NLR_PROP(float, 4, 4); else NLR_PROP(__half, 4, 4); }
+    else NLR_FAIL(NLR_ERR_UNSUPPORTED, "proposal MLP: grid L=%u C=%u not supported by the fused proposal kernel", gp.L, gp.C);
+#undef NLR_PROP
+    NLR_LAUNCH_CHECK("nlr_prop_kernel");
+    return NLR_OK;
+}

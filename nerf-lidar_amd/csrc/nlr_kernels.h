@@ -1,0 +1,71 @@
+// Kernel parameter blocks and internal launchers shared between the kernel files and nlr_api.hip.
+#pragma once
+#include "nlr_common.h"
+
+#define NLR_MAX_MULTI 16
+
+struct CastParams {
+    const float *origins, *directions, *base_x, *base_y, *radii;  // [N,3]/[N,1]
+    const float *tdist;      // [N, S+1]
+    const float *rand_deg;   // [N, S, n] uniform draws or null
+    uint32_t N, S, n;        // rays, samples per ray, multisamples
+    float std_scale;
+    float cosd[NLR_MAX_MULTI], sind[NLR_MAX_MULTI];  // cos/sin(2*pi*m*j/n), render.py:148
+    float degj[NLR_MAX_MULTI];                       // the angles themselves (rand path)
+};
+
+struct CompositeParams {
+    const float *density, *tdist, *dirs, *rgb, *sem, *inten, *far, *origins;
+    uint32_t N, S, K;
+    int opaque, extras;
+    float bg, scale_factor;
+    float *weights;  // [N,S] or null
+    float *o_rgb, *o_depth, *o_sem, *o_int, *o_acc, *o_dmean, *o_dmed, *o_p5, *o_p95, *o_points, *level_depth;
+    int32_t *o_labels;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct TileH {
+    bf16x8 f[2];  // 32 features x 32 samples as two k-steps of 16 (permuted k order, see pack_bf16)
+};
+
+struct MlpParams {
+    const float *feat;      // [M, F] f32
+    uint32_t M, S, F;       // samples, samples per ray, feature count
+    // packed f32 fragments: [kgroup][otile][lane] float4
+    const f32x4 *w_d0, *w_d2, *w_h1, *w_h2;
+    const float *b_d0, *b_d2, *b_h1, *b_h2;  // padded to 32*OT
+    // view MLP: packed fragments (bf16x8 or float4 depending on precision)
+    const void *w_v0, *w_v1a, *w_v1b, *w_vl, *w_rgb;  // w_vl: layers 2..D-1 back to back
+    const float *b_vl;      // [(D-2), W]
+    const float *b_rgb;     // [32]
+    const float *raybias;   // [N, 2, W] per-ray bias of layers 0 and 1 (bias + dir_enc columns)
+    uint32_t depth;         // net_depth_viewdirs
+    size_t vl_stride;       // elements (16 B units) between consecutive packed hidden layers
+    uint32_t K, int_row;    // class_num (0 = no semantic head), row of the intensity output (or 0xffffffff)
+    float density_bias, rgb_premul, rgb_bias, rgb_padding;
+    float *density, *rgb, *sem, *inten;  // outputs: [M], [M,3], [M,K], [M]
+};
+
+struct DirBiasParams {
+    const float *viewdirs;   // [N,3]
+    const float *wd0, *wd1;  // [W, E] dir-encoding columns of lin_second_stage_0 / _1
+    const float *b0, *b1;    // [W]
+    uint32_t N, W, deg, E;
+    float *out;              // [N, 2, W]
+};
+
+int nlr_launch_resample(const float *prev_sdist, const float *prev_weights, uint32_t n_prev, float dilation, float anneal,
+                        float pad, uint32_t S, const float *u_dev, const float *jitter, float max_jitter, const float *near,
+                        const float *far, float lam, uint32_t N, float *sdist, float *tdist, hipStream_t st);
+int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist, const float *rand_deg, uint32_t N,
+                         uint32_t S, uint32_t n, uint32_t mloops, float std_scale);
+int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, hipStream_t st);
+int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1, const float *b1, const float *w2, float b2,
+                    float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st);
+int nlr_launch_dirbias(const DirBiasParams &P, hipStream_t st);
+int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, bool view_f32, hipStream_t st);
+int nlr_launch_composite(const CompositeParams &P, hipStream_t st);

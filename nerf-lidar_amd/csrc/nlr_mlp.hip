@@ -1,0 +1,302 @@
+// NerfMLP evaluation on the matrix cores: density trunk -> semantic/intensity heads -> view MLP -> rgb.
+//
+// Replaces (rows a-9..a-12 of the scope table):
+//   ZI/models.py:887-889, 996-997, 1116     density_layer (F->64->256), softplus(raw - 1)
+//   ZI/models.py:954-961, 1124-1143         sem_layer (256->64->19, softmax), intensity_layer (256->64->1)
+//   ZI/coord.py:199-210, models.py:1190-1196  pos_enc(viewdirs) broadcast over samples
+//   ZI/models.py:939-951, 1223-1234, 1251   lin_second_stage_i (+skip concat after layer 0), rgb_layer, sigmoid, padding
+//
+// Design (CDNA4, not a translation of the nn.Linear chain):
+//   * the whole chain runs TRANSPOSED, activations^T = W . x^T, so that an MFMA result tile (32 output
+//     features x 32 samples: sample on the lane, features in the 16 accumulator registers) is already
+//     the B operand of the next layer's MFMA (cdna_hip_programming.md section 3, "An accumulator tile as
+//     the next MFMA's operand").  Activations never leave the register file: no LDS round trip, no
+//     barrier between the 8+ layers.  One wavefront owns 32 samples end to end.
+//   * weights are the A operand, pre-packed at model-create time into exactly the per-lane fragment
+//     order (including the permuted k order the accumulator layout implies), so every fragment fetch is
+//     one fully coalesced 16-byte-per-lane load of 1 KiB per wavefront.
+//   * the direction encoding is constant per ray, so its 27 input columns of layers 0 and 1 are folded
+//     into a per-ray bias by a small pre-kernel and every GEMM on the matrix cores has K % 32 == 0.
+//   * precision: layers whose error reaches depth / semantic argmax / intensity (density trunk, heads)
+//     use the exact-f32 MFMA (v_mfma_f32_32x32x2_f32); the view MLP (rgb only, 92 % of the MACs) uses
+//     bf16 MFMA (v_mfma_f32_32x32x16_bf16) with f32 accumulation.  NLR_PREC_F32 runs everything in f32.
+#include "nlr_kernels.h"
+
+
+// row of accumulator register r for lane half h inside a 32-row tile
+__device__ __forceinline__ int nlr_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int OT>
+__device__ __forceinline__ void nlr_acc_bias(f32x16 (&acc)[OT], const float *__restrict__ bias, int h) {
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(bias + o * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o][q * 4 + e] = v[e];
+        }
+}
+
+// acc[o] += W[o-tile, :] . in   on the exact-f32 MFMA.  KG = number of 8-feature k-groups.
+template <int OT, int KG, int KT>
+__device__ __forceinline__ void nlr_gemm_f32(f32x16 (&acc)[OT], const f32x16 (&in)[KT], const f32x4 *__restrict__ w, int lane) {
+    static_assert(KG <= KT * 4, "k-groups exceed the input tiles");
+    f32x4 a[2][OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) a[0][o] = w[o * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        if (g + 1 < KG) {
+#pragma unroll
+            for (int o = 0; o < OT; ++o) a[(g + 1) & 1][o] = w[((g + 1) * OT + o) * 64 + lane];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int o = 0; o < OT; ++o)
+                acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][o][e], in[g >> 2][(g & 3) * 4 + e], acc[o], 0, 0, 0);
+    }
+}
+
+// acc[o] += W[o-tile, :] . in   on the bf16 MFMA.  KG = number of 16-feature k-steps (= 2 per input tile).
+template <int OT, int KG, int KT>
+__device__ __forceinline__ void nlr_gemm_bf16(f32x16 (&acc)[OT], const TileH (&in)[KT], const bf16x8 *__restrict__ w, int lane) {
+    static_assert(KG <= KT * 2, "k-steps exceed the input tiles");
+    bf16x8 a[2][OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) a[0][o] = w[o * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        if (g + 1 < KG) {
+#pragma unroll
+            for (int o = 0; o < OT; ++o) a[(g + 1) & 1][o] = w[((g + 1) * OT + o) * 64 + lane];
+        }
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][o], in[g >> 1].f[g & 1], acc[o], 0, 0, 0);
+    }
+}
+
+template <int T, bool RELU>
+__device__ __forceinline__ void nlr_pack(TileH (&dst)[T], const f32x16 (&src)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = src[t][8 * s + j];
+                dst[t].f[s][j] = (__bf16)(RELU ? fmaxf(v, 0.0f) : v);
+            }
+}
+
+template <int T>
+__device__ __forceinline__ void nlr_relu(f32x16 (&x)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[t][r] = fmaxf(x[t][r], 0.0f);
+}
+
+// WT = view width / 32, BT = bottleneck / 32, FG = ceil(F/8), HT = head hidden tiles (0, 2 or 4)
+template <int WT, int BT, int FG, int HT, bool VIEW_F32>
+__global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const uint32_t sample = (blockIdx.x * 4 + wave) * 32 + col;
+    const bool valid = sample < P.M;
+    const uint32_t sc = valid ? sample : P.M - 1;
+    constexpr int FT = (FG + 3) / 4;
+
+    // ---- features -> accumulator-layout tiles (lane half h holds features 8q+4h..+3 of each group)
+    f32x16 fin[FT];
+#pragma unroll
+    for (int t = 0; t < FT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fin[t][r] = 0.0f;
+    {
+        const float *fp = P.feat + (size_t)sc * P.F;
+#pragma unroll
+        for (int g = 0; g < FG; ++g) {
+            const uint32_t f0 = 8 * g + 4 * h;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (f0 + 4 <= P.F) v = *reinterpret_cast<const f32x4 *>(fp + f0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fin[g >> 2][(g & 3) * 4 + e] = v[e];
+        }
+    }
+    // ---- density_layer.0 : F -> 64, ReLU
+    f32x16 hid[2];
+    nlr_acc_bias<2>(hid, P.b_d0, h);
+    nlr_gemm_f32<2, FG, FT>(hid, fin, P.w_d0, lane);
+    nlr_relu<2>(hid);
+    // ---- density_layer.2 : 64 -> bottleneck (no activation); row 0 is the raw density
+    f32x16 hb[BT];
+    nlr_acc_bias<BT>(hb, P.b_d2, h);
+    nlr_gemm_f32<BT, 8, 2>(hb, hid, P.w_d2, lane);
+    if (h == 0 && valid) {
+        const float x = hb[0][0] + P.density_bias;
+        P.density[sample] = x > 20.0f ? x : log1pf(expf(x));
+    }
+    // ---- semantic / intensity heads: bottleneck -> 64 (+64) -> [K logits | intensity]
+    if constexpr (HT > 0) {
+        f32x16 hh[HT];
+        nlr_acc_bias<HT>(hh, P.b_h1, h);
+        nlr_gemm_f32<HT, BT * 4, BT>(hh, hb, P.w_h1, lane);
+        nlr_relu<HT>(hh);
+        f32x16 lo[1];
+        nlr_acc_bias<1>(lo, P.b_h2, h);
+        nlr_gemm_f32<1, HT * 4, HT>(lo, hh, P.w_h2, lane);
+        if (P.K > 0) {  // softmax over rows [0,K) of this column, split over the two lane halves
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (nlr_row(r, h) < (int)P.K) mx = fmaxf(mx, lo[0][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float e[16], s = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                e[r] = 0.0f;
+                if (nlr_row(r, h) < (int)P.K) {
+                    e[r] = expf(lo[0][r] - mx);
+                    s += e[r];
+                }
+            }
+            s += __shfl_xor(s, 32, 64);
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (nlr_row(r, h) < (int)P.K) P.sem[(size_t)sample * P.K + nlr_row(r, h)] = e[r] / s;
+            }
+        }
+        if (P.inten && valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (nlr_row(r, h) == (int)P.int_row) P.inten[sample] = lo[0][r];
+        }
+    }
+    if (P.rgb == nullptr) return;  // density/semantic/intensity only
+
+    // ---- view MLP
+    const uint32_t ray = sc / P.S;
+    const float *rb0 = P.raybias + (size_t)ray * 2 * (WT * 32);
+    const float *rb1 = rb0 + WT * 32;
+    f32x16 acc[WT];
+    f32x16 out1[1];
+    if constexpr (!VIEW_F32) {
+        const bf16x8 *w_v0 = (const bf16x8 *)P.w_v0, *w_v1a = (const bf16x8 *)P.w_v1a, *w_v1b = (const bf16x8 *)P.w_v1b;
+        const bf16x8 *w_vl = (const bf16x8 *)P.w_vl, *w_rgb = (const bf16x8 *)P.w_rgb;
+        TileH hbh[BT];
+        nlr_pack<BT, false>(hbh, hb);
+        nlr_acc_bias<WT>(acc, rb0, h);
+        nlr_gemm_bf16<WT, BT * 2, BT>(acc, hbh, w_v0, lane);
+        TileH x[WT];
+        nlr_pack<WT, true>(x, acc);
+        nlr_acc_bias<WT>(acc, rb1, h);
+        nlr_gemm_bf16<WT, WT * 2, WT>(acc, x, w_v1a, lane);
+        nlr_gemm_bf16<WT, BT * 2, BT>(acc, hbh, w_v1b, lane);
+        nlr_pack<WT, true>(x, acc);
+        for (uint32_t l = 2; l < P.depth; ++l) {
+            nlr_acc_bias<WT>(acc, P.b_vl + (size_t)(l - 2) * (WT * 32), h);
+            nlr_gemm_bf16<WT, WT * 2, WT>(acc, x, w_vl + (size_t)(l - 2) * P.vl_stride, lane);
+            nlr_pack<WT, true>(x, acc);
+        }
+        nlr_acc_bias<1>(out1, P.b_rgb, h);
+        nlr_gemm_bf16<1, WT * 2, WT>(out1, x, w_rgb, lane);
+    } else {
+        const f32x4 *w_v0 = (const f32x4 *)P.w_v0, *w_v1a = (const f32x4 *)P.w_v1a, *w_v1b = (const f32x4 *)P.w_v1b;
+        const f32x4 *w_vl = (const f32x4 *)P.w_vl, *w_rgb = (const f32x4 *)P.w_rgb;
+        nlr_acc_bias<WT>(acc, rb0, h);
+        nlr_gemm_f32<WT, BT * 4, BT>(acc, hb, w_v0, lane);
+        f32x16 x[WT];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) x[t] = acc[t];
+        nlr_relu<WT>(x);
+        nlr_acc_bias<WT>(acc, rb1, h);
+        nlr_gemm_f32<WT, WT * 4, WT>(acc, x, w_v1a, lane);
+        nlr_gemm_f32<WT, BT * 4, BT>(acc, hb, w_v1b, lane);
+#pragma unroll
+        for (int t = 0; t < WT; ++t) x[t] = acc[t];
+        nlr_relu<WT>(x);
+        for (uint32_t l = 2; l < P.depth; ++l) {
+            nlr_acc_bias<WT>(acc, P.b_vl + (size_t)(l - 2) * (WT * 32), h);
+            nlr_gemm_f32<WT, WT * 4, WT>(acc, x, w_vl + (size_t)(l - 2) * P.vl_stride, lane);
+#pragma unroll
+            for (int t = 0; t < WT; ++t) x[t] = acc[t];
+            nlr_relu<WT>(x);
+        }
+        nlr_acc_bias<1>(out1, P.b_rgb, h);
+        nlr_gemm_f32<1, WT * 4, WT>(out1, x, w_rgb, lane);
+    }
+    if (h == 0 && valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float z = P.rgb_premul * out1[0][c] + P.rgb_bias;
+            const float sg = 1.0f / (1.0f + expf(-z));
+            P.rgb[(size_t)sample * 3 + c] = sg * (1.0f + 2.0f * P.rgb_padding) - P.rgb_padding;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-ray bias of view layers 0 and 1: b_l + W_l[:, dir columns] . pos_enc(viewdir)
+// ---------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) nlr_dirbias_kernel(DirBiasParams P) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.N * P.W) return;
+    const uint32_t ray = t / P.W, j = t - ray * P.W;
+    float e[3 + 6 * 8];
+    const float v[3] = {P.viewdirs[(size_t)ray * 3], P.viewdirs[(size_t)ray * 3 + 1], P.viewdirs[(size_t)ray * 3 + 2]};
+    // coord.py:199-210: [x, sin(2^k x), sin(2^k x + pi/2)], k-major
+    for (int c = 0; c < 3; ++c) e[c] = v[c];
+    for (uint32_t k = 0; k < P.deg; ++k)
+        for (int c = 0; c < 3; ++c) {
+            const float sx = v[c] * (float)(1u << k);
+            e[3 + k * 3 + c] = sinf(sx);
+            e[3 + 3 * P.deg + k * 3 + c] = sinf(sx + 1.57079637050628662f);
+        }
+    float a0 = P.b0[j], a1 = P.b1[j];
+    for (uint32_t i = 0; i < P.E; ++i) {
+        a0 = fmaf(P.wd0[(size_t)j * P.E + i], e[i], a0);
+        a1 = fmaf(P.wd1[(size_t)j * P.E + i], e[i], a1);
+    }
+    P.out[((size_t)ray * 2 + 0) * P.W + j] = a0;
+    P.out[((size_t)ray * 2 + 1) * P.W + j] = a1;
+}
+
+int nlr_launch_dirbias(const DirBiasParams &P, hipStream_t st) {
+    NLR_CHECK_ARG(P.deg <= 8, "deg_view %u > 8", P.deg);
+    const uint32_t T = P.N * P.W;
+    hipLaunchKernelGGL(nlr_dirbias_kernel, dim3((T + 255) / 256), dim3(256), 0, st, P);
+    NLR_LAUNCH_CHECK("nlr_dirbias_kernel");
+    return NLR_OK;
+}
+
+// Supported shapes are instantiated explicitly; everything else is reported, not silently emulated.
+int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, bool view_f32, hipStream_t st) {
+    NLR_CHECK_ARG(P.M > 0, "mlp: no samples");
+    const uint32_t FG = (P.F + 7) / 8;
+    dim3 grid((P.M + 127) / 128), block(256);
+#define NLR_MLP(WT, BT, FGv, HTv)                                                                             \
+    do {                                                                                                      \
+        if (view_f32) hipLaunchKernelGGL((nlr_mlp_kernel<WT, BT, FGv, HTv, true>), grid, block, 0, st, P);   \
+        else hipLaunchKernelGGL((nlr_mlp_kernel<WT, BT, FGv, HTv, false>), grid, block, 0, st, P);           \
+        NLR_LAUNCH_CHECK("nlr_mlp_kernel");                                                                   \
+        return NLR_OK;                                                                                        \
+    } while (0)
+    if (WB == 256 && FG == 5) {
+        if (W == 256 && HT == 4) NLR_MLP(8, 8, 5, 4);
+        if (W == 256 && HT == 2) NLR_MLP(8, 8, 5, 2);
+        if (W == 256 && HT == 0) NLR_MLP(8, 8, 5, 0);
+        if (W == 128 && HT == 4) NLR_MLP(4, 8, 5, 4);
+        if (W == 128 && HT == 2) NLR_MLP(4, 8, 5, 2);
+        if (W == 128 && HT == 0) NLR_MLP(4, 8, 5, 0);
+    }
+#undef NLR_MLP
+    NLR_FAIL(NLR_ERR_UNSUPPORTED,
+             "NerfMLP shape (width %u, bottleneck %u, %u grid features, %u head tiles) has no fused kernel instance; "
+             "instantiated: width in {128,256}, bottleneck 256, 40 grid features",
+             W, WB, P.F, HT);
+}

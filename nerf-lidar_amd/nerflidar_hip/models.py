@@ -1,0 +1,332 @@
+"""Host-side mirror of the reference's render entry points, running on libnerflidar_hip.so.
+
+`Model.forward` and `render_image` keep the signatures and return structures of
+ZI/models.py:239-251,576 and ZI/models.py:1379-1507; all arithmetic of the level loop (resample ->
+cast -> encode -> MLP -> composite) happens in one `nlr_render_rays` call per chunk.  PyTorch is
+used only for device memory and streams.  There is no eager/CPU fallback: without the HIP
+library or without a GPU these classes raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import MLPConfig, ModelConfig
+from .weights import grid_layout, mlp_names, mlp_param_shapes
+
+_RAY_KEYS = ("origins", "directions", "viewdirs", "radii", "near", "far", "base_x", "base_y")
+
+
+def _f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class Model:
+    """Drop-in for ZI/models.py:Model at inference (instance_obj=False, num_glo_features=0).
+
+    Args:
+      mc: ModelConfig (gin names).  state_dict: reference-keyed parameters (numpy or torch, any
+      device); hash tables are kept as float32 (or float16 if `table_dtype=torch.float16`) CUDA
+      tensors in `self.tables[prefix]`, MLP weights are packed once into MFMA fragment order by
+      `nlr_model_create`.
+    """
+
+    def __init__(self, mc: ModelConfig, state_dict: Dict[str, object], device="cuda:0",
+                 precision: int = _lib.PREC_MIXED, table_dtype=torch.float32):
+        if mc.config.instance_obj:
+            raise NotImplementedError("instance_obj=True (dynamic-object branch, ZI/models.py:306-315,401-477) "
+                                      "is outside the fused path (SURVEY section 8f-1)")
+        if mc.raydist_fn != "power_transformation":
+            raise NotImplementedError("only raydist_fn='power_transformation' (the gin value) is supported")
+        self.mc = mc
+        self.config = mc.config
+        self.device = torch.device(device)
+        self.precision = precision
+        self.training = False
+        self.num_levels = mc.num_levels
+        self.tables: Dict[str, torch.Tensor] = {}
+        self._keep = []  # host arrays referenced by the descriptor during nlr_model_create
+        self._handle = C.c_void_p(None)
+        self._ws: Optional[torch.Tensor] = None
+        sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in state_dict.items()}
+        desc = _lib.NlrModelDesc()
+        desc.num_levels = mc.num_levels
+        samples = mc.level_samples()
+        mlp_descs = []
+        for li, (prefix, cfg) in enumerate(mlp_names(mc)):
+            desc.num_samples[li] = samples[li]
+            md = self._mlp_desc(prefix, cfg, sd, table_dtype)
+            mlp_descs.append(md)
+            desc.mlps[li] = C.pointer(md)
+        desc.dilation_multiplier = mc.dilation_multiplier
+        desc.dilation_bias = mc.dilation_bias
+        desc.anneal_slope = mc.anneal_slope
+        desc.resample_padding = mc.resample_padding
+        desc.power_lambda = mc.power_lambda
+        desc.std_scale = mc.std_scale
+        lo, hi = mc.bg_intensity_range
+        desc.bg_intensity = lo if lo == hi else (lo + hi) / 2  # models.py:488-493 (deterministic render)
+        desc.opaque_background = int(mc.opaque_background)
+        desc.mlp_precision = precision
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().nlr_model_create(C.byref(desc), C.byref(self._handle), _lib.current_stream())
+        _lib.check(rc, "nlr_model_create")
+        self._keep.clear()
+
+    # -- descriptor assembly ---------------------------------------------------------------------
+    def _linear(self, sd, name) -> _lib.NlrLinear:
+        w, b = _f32c(sd[name + ".weight"]), _f32c(sd[name + ".bias"])
+        self._keep += [w, b]
+        l = _lib.NlrLinear()
+        l.weight = w.ctypes.data
+        l.bias = b.ctypes.data
+        l.out_features, l.in_features = w.shape
+        return l
+
+    def _mlp_desc(self, prefix: str, cfg: MLPConfig, sd, table_dtype) -> _lib.NlrMlpDesc:
+        md = _lib.NlrMlpDesc()
+        offsets, _, pls = grid_layout(cfg)
+        emb = sd[f"{prefix}.encoder.embeddings"]
+        if emb.shape != (int(offsets[-1]), cfg.grid_level_dim):
+            raise RuntimeError(f"{prefix}.encoder.embeddings has shape {emb.shape}, expected "
+                               f"{(int(offsets[-1]), cfg.grid_level_dim)}")
+        table = torch.from_numpy(_f32c(emb)).to(self.device, table_dtype).contiguous()
+        self.tables[prefix] = table
+        off = np.ascontiguousarray(offsets, np.int32)
+        self._keep.append(off)
+        g = md.grid
+        g.table = table.data_ptr()
+        g.table_dtype = 0 if table_dtype == torch.float32 else 1
+        g.num_levels, g.level_dim = cfg.grid_num_levels, cfg.grid_level_dim
+        g.base_resolution = cfg.grid_base_resolution
+        g.log2_per_level_scale = float(np.log2(pls))
+        g.offsets = off.ctypes.data
+        g.gridtype, g.align_corners, g.interp = 0, 0, 0
+        md.density0 = self._linear(sd, f"{prefix}.density_layer.0")
+        md.density2 = self._linear(sd, f"{prefix}.density_layer.2")
+        md.disable_rgb = int(cfg.disable_rgb)
+        md.bottleneck_width = cfg.bottleneck_width
+        md.net_depth_viewdirs, md.net_width_viewdirs = cfg.net_depth_viewdirs, cfg.net_width_viewdirs
+        md.skip_layer_dir, md.deg_view = cfg.skip_layer_dir, cfg.deg_view
+        md.density_bias, md.rgb_premultiplier = cfg.density_bias, cfg.rgb_premultiplier
+        md.rgb_bias, md.rgb_padding = cfg.rgb_bias, cfg.rgb_padding
+        md.re_weights = int(cfg.re_weights)
+        md.class_num = cfg.class_num
+        if not cfg.disable_rgb:
+            if cfg.net_depth_viewdirs > _lib.NLR_MAX_VIEW_DEPTH:
+                raise RuntimeError("net_depth_viewdirs too large")
+            for i in range(cfg.net_depth_viewdirs):
+                md.view[i] = self._linear(sd, f"{prefix}.lin_second_stage_{i}")
+            md.rgb_layer = self._linear(sd, f"{prefix}.rgb_layer")
+            md.use_semantic, md.no_sem_layer = int(cfg.use_semantic), int(cfg.no_sem_layer)
+            if cfg.use_semantic and not cfg.no_sem_layer:
+                md.sem0 = self._linear(sd, f"{prefix}.sem_layer.0")
+                md.sem2 = self._linear(sd, f"{prefix}.sem_layer.2")
+            md.use_intensity = int(cfg.use_intensity)
+            if cfg.use_intensity:
+                md.int0 = self._linear(sd, f"{prefix}.intensity_layer.0")
+                md.int2 = self._linear(sd, f"{prefix}.intensity_layer.2")
+        return md
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.lib().nlr_model_destroy(self._handle)
+                self._handle = C.c_void_p(None)
+        except Exception:
+            pass
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    # -- the fused op --------------------------------------------------------------------------
+    def _workspace(self, n: int) -> torch.Tensor:
+        need = _lib.lib().nlr_workspace_bytes(self._handle, n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def render_rays(self, batch: Dict[str, torch.Tensor], train_frac: float = 1.0, compute_extras: bool = True,
+                    sample_n: int = 7, sample_m: int = 3, want_history: bool = False, scale_factor: float = 0.0,
+                    rand_jitter: Optional[List[torch.Tensor]] = None, rand_deg: Optional[List[torch.Tensor]] = None):
+        """One `nlr_render_rays` call.  Returns (rendering dict of the last level, list of per-level dicts)."""
+        rays = _lib.NlrRays()
+        n = batch["origins"].shape[0]
+        keep = []
+        for k in _RAY_KEYS:
+            t = batch.get(k)
+            if t is None:
+                raise RuntimeError(f"batch['{k}'] is missing")
+            if not t.is_cuda:
+                raise RuntimeError(f"batch['{k}'] must be a CUDA tensor (no CPU fallback)")
+            t = t.reshape(n, -1).contiguous().float()
+            keep.append(t)
+            setattr(rays, k, t.data_ptr())
+        dev, f32 = self.device, torch.float32
+        K = self.mc.nerf_mlp.class_num if self.config.use_semantic else 0
+        new = lambda *shape, dtype=f32: torch.empty(*shape, device=dev, dtype=dtype)
+        out = _lib.NlrOut()
+        r: Dict[str, torch.Tensor] = {"rgb": new(n, 3), "depth": new(n)}
+        if K:
+            r["semantic"] = new(n, K)
+        if self.config.use_intensity:
+            r["intensity"] = new(n)
+        if compute_extras:
+            for k in ("acc", "distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
+                r[k] = new(n)
+        if scale_factor > 0:
+            r["points"] = new(n, 3)
+            if K:
+                r["labels"] = new(n, dtype=torch.int32)
+        for k, t in r.items():
+            setattr(out, k, t.data_ptr())
+        hist: List[Dict[str, torch.Tensor]] = []
+        samples = self.mc.level_samples()
+        for li, S in enumerate(samples):
+            h: Dict[str, torch.Tensor] = {"depth": new(n)}
+            if want_history:
+                h.update(sdist=new(n, S + 1), tdist=new(n, S + 1), weights=new(n, S), density=new(n, S))
+                if li == len(samples) - 1:
+                    h["rgb"] = new(n, S, 3)
+                    if K:
+                        h["semantic"] = new(n, S, K)
+                    if self.config.use_intensity:
+                        h["intensity"] = new(n, S)
+            for k, t in h.items():
+                setattr(out.history[li], k, t.data_ptr())
+            hist.append(h)
+        cfg = _lib.NlrRenderCfg()
+        cfg.train_frac = float(train_frac)
+        cfg.compute_extras = int(compute_extras)
+        cfg.sample_n, cfg.sample_m = sample_n, sample_m
+        cfg.scale_factor = float(scale_factor)
+        for li in range(len(samples)):
+            if rand_jitter is not None:
+                t = rand_jitter[li].reshape(n).contiguous().float()
+                keep.append(t)
+                cfg.rand_jitter[li] = t.data_ptr()
+            if rand_deg is not None:
+                t = rand_deg[li].reshape(n, samples[li], sample_n).contiguous().float()
+                keep.append(t)
+                cfg.rand_deg[li] = t.data_ptr()
+        with torch.cuda.device(dev):
+            ws = self._workspace(n)
+            rc = _lib.lib().nlr_render_rays(self._handle, C.byref(rays), n, C.byref(cfg), C.byref(out),
+                                            _lib.ptr(ws), ws.numel(), _lib.current_stream())
+        _lib.check(rc, "nlr_render_rays")
+        return r, hist
+
+    # -- reference-compatible call --------------------------------------------------------------
+    def forward(self, rand, batch, train_frac, compute_extras, zero_glo=True, sample_n=7, sample_m=3, step=0,
+                max_step=25000, curr_track=None):
+        """ZI/models.py:239-576.  Returns (renderings, ray_history), one entry per level.
+
+        `rand`: falsy for deterministic rendering; otherwise a torch.Generator (or True) used to draw the
+        per-ray jitter (stepfun.py:216) and per-multisample rotation (render.py:150) on the device.
+        Proposal-level `renderings` carry only what consumers read from them (`depth`, ray_* bundles);
+        the full set of keys is produced for the last level (render consumers read `renderings[-1]`,
+        models.py:1460).
+        """
+        n = batch["origins"].shape[0]
+        samples = self.mc.level_samples()
+        rj = rd = None
+        if rand:
+            gen = rand if isinstance(rand, torch.Generator) else None
+            rj = [torch.rand(n, 1, device=self.device, generator=gen) for _ in samples]
+            rd = [torch.rand(n, S, sample_n, device=self.device, generator=gen) for S in samples]
+        r, hist = self.render_rays(batch, train_frac, compute_extras, sample_n, sample_m, want_history=True,
+                                   rand_jitter=rj, rand_deg=rd)
+        renderings = []
+        for li, h in enumerate(hist):
+            last = li == len(hist) - 1
+            rend = dict(r) if last else {"depth": h["depth"]}
+            if compute_extras:
+                nv = self.config.vis_num_rays
+                rend["ray_sdist"] = h["sdist"][:nv]
+                rend["ray_weights"] = h["weights"][:nv]
+                rend["ray_rgbs"] = hist[-1]["rgb"][:nv] if last else None
+            renderings.append(rend)
+        if compute_extras:  # models.py:559-570: proposal levels show the final average colour
+            final_rgb = torch.sum(renderings[-1]["ray_rgbs"] * renderings[-1]["ray_weights"][..., None], dim=-2)
+            for li in range(len(hist) - 1):
+                S = samples[li]
+                renderings[li]["ray_rgbs"] = torch.broadcast_to(final_rgb[:, None, :], (final_rgb.shape[0], S, 3))
+        ray_history = [{k: v for k, v in h.items() if k != "depth"} for h in hist]
+        return renderings, ray_history
+
+    __call__ = forward
+
+
+class _SingleProcess:
+    """Stand-in for accelerate.Accelerator when rendering in one process."""
+    process_index = 0
+    num_processes = 1
+    is_main_process = True
+
+    def gather(self, t):
+        return t
+
+
+@torch.no_grad()
+def render_image(model: Model, accelerator, batch, rand, config, train_frac=1, verbose=True, return_weights=False,
+                 image=True, render_instance=False, instance_id=None):
+    """ZI/models.py:1379-1507: flatten, chunk by `config.render_chunk_size`, pad to a multiple of the process
+    count, rank slice, forward, gather, strip pad, concat, reshape.  `accelerator` may be None (one process)
+    or any object with `process_index`, `num_processes`, `gather` (accelerate.Accelerator works)."""
+    if render_instance:
+        raise NotImplementedError("render_instance (obj_rendering) is outside the fused path")
+    acc = accelerator or _SingleProcess()
+    model.eval()
+    if image:
+        height, width = batch["origins"].shape[:2]
+        num_rays = height * width
+    else:
+        num_rays = batch["origins"].shape[0]
+    batch = {k: v.reshape((num_rays, -1)) for k, v in batch.items() if v is not None}
+    rank, world = acc.process_index, acc.num_processes
+    chunks = []
+    for idx0 in range(0, num_rays, config.render_chunk_size):
+        cb = {k: v[idx0:idx0 + config.render_chunk_size] for k, v in batch.items()}
+        actual = cb["origins"].shape[0]
+        rem = actual % world
+        padding = world - rem if rem else 0
+        if padding:
+            cb = {k: torch.cat([v, torch.zeros_like(v[-padding:])], dim=0) for k, v in cb.items()}
+        per = cb["origins"].shape[0] // world
+        cb = {k: v[rank * per:(rank + 1) * per] for k, v in cb.items()}
+        renderings, ray_history = model(rand, cb, train_frac=train_frac, compute_extras=True, zero_glo=True)
+        gather = lambda v: acc.gather(v.contiguous())[:-padding] if padding > 0 else acc.gather(v.contiguous())
+        renderings = [{k: gather(v) for k, v in r.items()} for r in renderings]
+        cr = renderings[-1]
+        for k in renderings[0]:
+            if k.startswith("ray_"):
+                cr[k] = [r[k] for r in renderings]
+        if return_weights:
+            cr["weights"] = gather(ray_history[-1]["weights"])
+        chunks.append(cr)
+    rendering = {}
+    for k in chunks[0].keys():
+        if isinstance(chunks[0][k], list):
+            rendering[k] = [torch.cat([c[k][i] for c in chunks]) for i in range(len(chunks[0][k]))]
+        else:
+            rendering[k] = torch.cat([c[k] for c in chunks])
+    for k, z in rendering.items():
+        if not k.startswith("ray_") and "hash" not in k:
+            rendering[k] = z.reshape((height, width) + z.shape[1:]) if image else z.reshape(num_rays, -1)
+    keys = [k for k in rendering if k.startswith("ray_")]
+    if keys:
+        nr = rendering[keys[0]][0].shape[0]
+        ray_idx = torch.randperm(nr)[:config.vis_num_rays]
+        for k in keys:
+            rendering[k] = [r[ray_idx.to(r.device)] for r in rendering[k]]
+    model.train()
+    return rendering

@@ -1,0 +1,113 @@
+"""CPU-side checks of the product's host code: the C-ABI library loads and exports every symbol the header
+declares, host helpers agree with torch / the oracle, the gin-lite reader and config names, and the
+multi-process (gloo, world_size 2) path of the azimuth-sharded driver.  No GPU compute is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from nerflidar_hip import _lib, config as nconfig, lidar as nlidar, weights as nweights
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "nerflidar_hip.h")).read()
+    declared = set(re.findall(r"\b(nlr_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/nerflidar_hip.h but not exported"
+    assert set(_lib.EXPORTS) == declared
+    assert L.nlr_version() >= 100
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors must have the C layout (pointer/uint32 packing)."""
+    assert C.sizeof(_lib.NlrLinear) == 24
+    assert C.sizeof(_lib.NlrGridDesc) == 56
+    assert C.sizeof(_lib.NlrRays) == 64
+    assert C.sizeof(_lib.NlrLevelOut) == 64
+    assert C.sizeof(_lib.NlrOut) == 11 * 8 + 4 * 64
+    assert C.sizeof(_lib.NlrRenderCfg) == 16 + 2 * 32 + 8
+
+
+def test_sample_u_matches_torch_linspace():
+    L = _lib.lib()
+    eps = float(torch.finfo(torch.float32).eps)
+    for n in (2, 7, 32, 64, 128, 256):
+        for rand in (0, 1):
+            u = np.zeros(n, np.float32)
+            mj = C.c_float(0)
+            L.nlr_sample_u(n, rand, u.ctypes.data, C.addressof(mj))
+            if not rand:
+                pad = 1 / (2 * n)
+                ref = torch.linspace(pad, 1. - pad - eps, n).numpy()
+            else:
+                u_max = eps + (1 - eps) / n
+                ref = torch.linspace(0, 1 - u_max, n).numpy()
+                assert np.float32((1 - u_max) / (n - 1) - eps) == np.float32(mj.value)
+            # ATen's vectorised linspace and its scalar formula differ by at most one ulp
+            np.testing.assert_allclose(u, ref, atol=1.2e-7, rtol=0)
+            assert (np.diff(u) > 0).all()
+
+
+def test_level_scale_matches_oracle():
+    from oracle import nlr_oracle as orc
+    L = _lib.lib()
+    for S, H, n in ((1.0, 16, 10), (0.5849625, 16, 12), (1.0, 16, 8)):
+        sc, rs = np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        L.nlr_level_scale(n, S, H, sc.ctypes.data, rs.ctypes.data)
+        osc, ors = orc.level_scale(n, S, H)
+        np.testing.assert_array_equal(sc, osc)
+        np.testing.assert_array_equal(rs, ors)
+
+
+def test_gin_lite_reads_shipped_bindings():
+    text = """
+    Config.use_semantic = True
+    Config.no_sem_layer = False
+    Model.raydist_fn = 'power_transformation'
+    Model.opaque_background = True
+    Model.num_nerf_samples = 128
+    Model.num_prop_samples = (256, 64)   # render_video.py:130
+    PropMLP.disable_rgb = True
+    PropMLP.grid_level_dim = 1
+    NerfMLP.net_depth_viewdirs = 8
+    NerfMLP.net_width_viewdirs = 256
+    ObjMLP.bottleneck_width = 64         # ignored scope
+    Config.unknown_field = 3             # ignored field
+    """
+    mc = nconfig.parse_gin_bindings(text)
+    assert mc.num_nerf_samples == 128 and mc.num_prop_samples == (256, 64)
+    assert mc.nerf_mlp.net_depth_viewdirs == 8 and mc.nerf_mlp.use_semantic and not mc.nerf_mlp.no_sem_layer
+    assert mc.level_samples() == [256, 64, 128]
+
+
+def test_mac_counts_match_survey():
+    """Algorithmic MACs/sample used by bench.py's roofline."""
+    from nerflidar_hip.flops import macs_per_sample, flops_per_ray
+    assert macs_per_sample(nconfig.workload("C2").nerf_mlp) == 657408
+    # C1 (4x128 + semantic head): 18944 + 36224 + 52608 + 2*16384 + 384 + 17600 (SURVEY 8d quotes 117632, which
+    # does not correspond to the layer shapes of ZI/models.py:939-957; the shapes are authoritative)
+    assert macs_per_sample(nconfig.workload("C1").nerf_mlp) == 158528
+    assert macs_per_sample(nconfig.workload("REF").prop_cfg(0)) == 448
+    assert macs_per_sample(nconfig.workload("REF").prop_cfg(1)) == 576
+    # REF: the shipped gin has use_intensity=False -> 247744 MACs/sample for the NerfMLP (SURVEY counts the
+    # intensity head in too: 264192); 2*(64*448 + 64*576 + 32*247744)
+    assert flops_per_ray(nconfig.workload("REF")) == 2 * (64 * 448 + 64 * 576 + 32 * 247744)
+    assert flops_per_ray(nconfig.workload("C2")) == 2 * (64 * 448 + 64 * 576 + 128 * 657408)
+    assert abs(flops_per_ray(nconfig.workload("C2S")) / 1e6 - 168.3) < 0.05
+
+
+def test_azimuth_sector_partition():
+    b = nlidar.synthetic_sweep(width=20, seed=0, beams=nlidar.LIDAR_ANGLES[:4])
+    parts = [nlidar.azimuth_sector(b, 4, 20, r, 3) for r in range(3)]
+    wp = parts[0][1]
+    assert wp == 7
+    img = np.concatenate([p[0]["directions"].reshape(4, wp, 3) for p in parts], axis=1)[:, :20]
+    np.testing.assert_array_equal(img.reshape(-1, 3), b["directions"])
+    # viewdirs keep the full-sweep Frobenius norm (quirk), so a sector renders identically to the full sweep
+    np.testing.assert_array_equal(parts[1][0]["viewdirs"][0], b["viewdirs"][7])
