@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- LiDAR rays/s of the MI355X-native render hot path (BASELINE.json metric).
+
+A step = one pass of the whole hot path (all proposal levels + NerfMLP level + compositing, outputs resident in
+HBM) over one synthetic nuScenes-shaped sweep sector of 32 beams x 1024 azimuth columns (32 768 rays) per GPU,
+configuration C2 of BASELINE.json: (64, 64, 128) samples per ray, 8x256 view MLP, semantic + intensity heads,
+full-size hash tables (229 MiB NerfMLP table, fp32).  With N > 1 the sweep has 1024*N azimuth columns, GPU p
+renders sector p and ONE all-gather (RCCL) reassembles the packed [32, 1024*N, 7] range image on every rank
+(weak scaling: per-GPU work fixed).
+
+    python bench.py --gpus N --steps K --warmup W         (N > 1: under torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0; carries `roofline` for the dominant kernel (nlr_mlp_kernel, timed with HIP
+events on its own stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nerf-lidar_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from nerflidar_hip import _lib, config as nconfig, flops as nflops, lidar as nlidar, sharding, weights as nweights
+from nerflidar_hip.models import Model
+
+H_BEAMS, W_COLS = 32, 1024
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+KNAMES = ["resample", "prop", "encode", "dirbias", "mlp", "composite"]
+
+
+def cpu_baseline(mc, sd, batch_np, n_rays, threads):
+    """The oracle (a port: PyTorch-CPU restatement pinned on reference fixtures) timed on this host's cores."""
+    from oracle import nlr_oracle as orc
+    torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    idx = np.linspace(0, batch_np["origins"].shape[0] - 1, n_rays).astype(np.int64)
+    b = {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in batch_np.items()}
+    enc = orc.make_encoders(sd, mc)
+    sdt = orc.to_torch_sd(sd)
+    chunk = 1024
+    def run():
+        for i in range(0, n_rays, chunk):
+            orc.model_forward(sd, mc, {k: v[i:i + chunk] for k, v in b.items()}, encoders=enc, sd_t=sdt)
+    with torch.no_grad():
+        orc.model_forward(sd, mc, {k: v[:256] for k, v in b.items()}, encoders=enc, sd_t=sdt)  # warm-up
+        t0 = time.perf_counter()
+        run()
+        dt = time.perf_counter() - t0
+    return dict(value=n_rays / dt, unit="rays/s", cores=threads, kind="port",
+                sample=f"{n_rays} rays of the same sweep (every {len(batch_np['origins']) // n_rays}th ray), "
+                       f"same weights, chunks of {chunk}, {dt:.1f} s of wall time, fp32 PyTorch-CPU + OpenMP C grid oracle")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--precision", type=int, default=_lib.PREC_MIXED)
+    ap.add_argument("--log2-hashmap", type=int, default=None, help="shrink the hash tables (debug only)")
+    ap.add_argument("--cpu-rays", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    mc = nconfig.workload(args.workload, args.log2_hashmap)
+    sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
+    model = Model(mc, sd, device=dev, precision=args.precision)
+    width = W_COLS * world
+    full = nlidar.synthetic_sweep(width=width, seed=0)
+    sec, wp = nlidar.azimuth_sector(full, H_BEAMS, width, rank, world)
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in sec.items()}
+    n_rays = H_BEAMS * wp
+    sf = 1.0 / 250.0
+
+    def step():
+        r, _ = model.render_rays(batch, compute_extras=True, scale_factor=sf)
+        tile = sharding.pack_tile(r, H_BEAMS, wp)
+        return sharding.gather_tiles(tile, width)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    L = _lib.lib()
+    L.nlr_profile_begin(model._handle)  # HIP events on the launch stream around every kernel of the timed steps
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ms = (C.c_float * _lib.NLR_K_COUNT)()
+    cnt = (C.c_uint32 * _lib.NLR_K_COUNT)()
+    _lib.check(L.nlr_profile_end(model._handle, _lib.current_stream(), ms, cnt), "nlr_profile_end")
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    assert img.shape == (H_BEAMS, width, 7)
+
+    if rank == 0:
+        rays_total = n_rays * world * args.steps
+        kern = {KNAMES[i]: (ms[i] / cnt[i] if cnt[i] else 0.0) for i in range(_lib.NLR_K_COUNT)}
+        # dominant kernel: nlr_mlp_kernel.  Algorithmic FLOPs per launch = 2 * MACs/sample (SURVEY 8d:
+        # 657 408 for the 8x256 NerfMLP + heads) * samples per launch (rays * 128).
+        S_last = mc.level_samples()[-1]
+        fl_launch = 2.0 * nflops.macs_per_sample(mc.nerf_mlp) * n_rays * S_last
+        mlp_s = kern["mlp"] * 1e-3
+        achieved = fl_launch / mlp_s / 1e12 if mlp_s > 0 else 0.0
+        out = {
+            "metric": "LiDAR rays/sec @128 samples/ray, 8x256 MLP; depth L1 vs reference",
+            "value": rays_total / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 (sampling, hash grid, density/semantic/intensity layers on f32 MFMA) + bf16 MFMA (view MLP)"
+                     if args.precision == _lib.PREC_MIXED else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: nuScenes 32-beam sweep, 32x1024 rays per GPU, samples (64,64,128), "
+                                   "8x256 NerfMLP + semantic + intensity heads, full-size fp32 hash tables",
+                       "rays_per_gpu_per_step": n_rays, "azimuth_columns_total": width,
+                       "parallelism": f"azimuth-sector x{world}" + (" + 1 all_gather of the packed range image" if world > 1 else ""),
+                       "flops_per_ray": nflops.flops_per_ray(mc), "gather_bytes_per_ray": nflops.gather_bytes_per_ray(mc)},
+            "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+            "roofline": {"kernel": "nlr_mlp_kernel", "bound": "mfma", "achieved": achieved,
+                         "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = len(os.sched_getaffinity(0))
+            out["cpu_baseline"] = cpu_baseline(mc, sd, sec, args.cpu_rays, threads)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -188,9 +188,18 @@ size_t nlr_workspace_bytes(const NlrModel *m, uint32_t N);
 int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t N, const NlrRenderCfg *cfg,
                     const NlrOut *out, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Name + average duration bookkeeping is left to rocprofv3; these return the kernel names the
- * library launches so bench.py can match the trace rows.  Host only. */
+/* Comma-separated names of the kernels the library launches, in NLR_K_* order (host only), so that
+ * bench.py can match rocprofv3 --kernel-trace rows. */
 const char *nlr_kernel_names(void);
+
+/* Per-kernel timing with HIP events recorded on the SAME stream the kernels are launched on.
+ * nlr_profile_begin arms the model: every launch made by nlr_render_rays / nlr_mlp_level is then
+ * bracketed by an event pair.  nlr_profile_end synchronises the stream, writes total milliseconds and
+ * launch counts per kernel kind (arrays of NLR_K_COUNT) and disarms.  Costs two hipEventRecord per
+ * launch while armed; nothing when not armed. */
+enum { NLR_K_RESAMPLE = 0, NLR_K_PROP = 1, NLR_K_ENCODE = 2, NLR_K_DIRBIAS = 3, NLR_K_MLP = 4, NLR_K_COMPOSITE = 5, NLR_K_COUNT = 6 };
+int nlr_profile_begin(NlrModel *m);
+int nlr_profile_end(NlrModel *m, void *stream, float *total_ms, uint32_t *launches);
 
 /* ------------------------------------------------------------------------------------------
  * (4) Stage entry points: the same kernels nlr_render_rays chains, exposed one by one so each

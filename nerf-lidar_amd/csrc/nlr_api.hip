@@ -17,9 +17,31 @@ void nlr_set_error(const char *fmt, ...) {
 extern "C" const char *nlr_last_error(void) { return g_err; }
 extern "C" int nlr_version(void) { return 100; }
 extern "C" const char *nlr_kernel_names(void) {
-    return "nlr_resample_kernel,nlr_prop_kernel,nlr_encode_kernel,nlr_dirbias_kernel,nlr_mlp_kernel,nlr_composite_kernel,"
-           "nlr_grid_fwd_kernel,nlr_grid_bwd_kernel,nlr_grid_input_bwd_kernel";
+    return "nlr_resample_kernel,nlr_prop_kernel,nlr_encode_kernel,nlr_dirbias_kernel,nlr_mlp_kernel,nlr_composite_kernel";
 }
+
+// ---- optional per-kernel event timing ---------------------------------------------------------------
+struct Profile {
+    bool armed = false;
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+    std::vector<int> kind;
+};
+struct ProfScope {  // RAII bracket around one launch
+    Profile *p;
+    hipStream_t st;
+    ProfScope(Profile *prof, int kind, hipStream_t s) : p(prof && prof->armed ? prof : nullptr), st(s) {
+        if (!p) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { p = nullptr; return; }
+        p->ev.push_back(a);
+        p->ev.push_back(b);
+        p->kind.push_back(kind);
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() {
+        if (p) (void)hipEventRecord(p->ev.back(), st);
+    }
+};
 
 // ---- model ------------------------------------------------------------------------------------------
 struct LevelModel {
@@ -51,6 +73,7 @@ struct NlrModel {
     float dilation_multiplier, dilation_bias, anneal_slope, resample_padding, power_lambda, std_scale, bg;
     uint32_t opaque, prec;
     std::vector<void *> allocs;
+    mutable Profile prof;
 };
 
 static int dev_upload(NlrModel *m, const void *host, size_t bytes, void **out) {
@@ -327,7 +350,7 @@ extern "C" int nlr_model_create(const NlrModelDesc *desc, NlrModel **out, void *
 
 extern "C" void nlr_model_destroy(NlrModel *m) {
     if (!m) return;
-    for (void *p : m->allocs) hipFree(p);
+    for (void *p : m->allocs) (void)hipFree(p);
     delete m;
 }
 
@@ -336,6 +359,35 @@ extern "C" int nlr_model_set_table(NlrModel *m, uint32_t level, const void *tabl
     NLR_CHECK_ARG(table_dtype == 0 || table_dtype == 1, "model_set_table: table_dtype must be 0 or 1");
     m->lv[level].gp.table = table_dev;
     m->lv[level].gp.table_dtype = table_dtype;
+    return NLR_OK;
+}
+
+extern "C" int nlr_profile_begin(NlrModel *m) {
+    NLR_CHECK_ARG(m != nullptr, "profile_begin: NULL model");
+    for (hipEvent_t e : m->prof.ev) (void)hipEventDestroy(e);
+    m->prof.ev.clear();
+    m->prof.kind.clear();
+    m->prof.armed = true;
+    return NLR_OK;
+}
+
+extern "C" int nlr_profile_end(NlrModel *m, void *stream, float *total_ms, uint32_t *launches) {
+    NLR_CHECK_ARG(m && total_ms && launches, "profile_end: NULL argument");
+    m->prof.armed = false;
+    NLR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    for (int k = 0; k < NLR_K_COUNT; ++k) {
+        total_ms[k] = 0.0f;
+        launches[k] = 0;
+    }
+    for (size_t i = 0; i < m->prof.kind.size(); ++i) {
+        float ms = 0.0f;
+        NLR_HIP(hipEventElapsedTime(&ms, m->prof.ev[2 * i], m->prof.ev[2 * i + 1]));
+        total_ms[m->prof.kind[i]] += ms;
+        launches[m->prof.kind[i]] += 1;
+    }
+    for (hipEvent_t e : m->prof.ev) (void)hipEventDestroy(e);
+    m->prof.ev.clear();
+    m->prof.kind.clear();
     return NLR_OK;
 }
 
@@ -383,8 +435,14 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     CastParams cp;
     int rc = nlr_fill_cast_params(&cp, rays, tdist, rand_deg, N, lv.S, n, mloops, m->std_scale);
     if (rc) return rc;
-    if (lv.is_prop) return nlr_launch_prop(cp, lv.gp, lv.p_w1, lv.p_b1, lv.p_w2, lv.p_b2, lv.density_bias, lv.re_weights, density, prop_feat, st);
-    if ((rc = nlr_launch_encode(cp, lv.gp, lv.re_weights, feat, st))) return rc;
+    if (lv.is_prop) {
+        ProfScope ps(&m->prof, NLR_K_PROP, st);
+        return nlr_launch_prop(cp, lv.gp, lv.p_w1, lv.p_b1, lv.p_w2, lv.p_b2, lv.density_bias, lv.re_weights, density, prop_feat, st);
+    }
+    {
+        ProfScope ps(&m->prof, NLR_K_ENCODE, st);
+        if ((rc = nlr_launch_encode(cp, lv.gp, lv.re_weights, feat, st))) return rc;
+    }
     if (rgb) {
         NLR_CHECK_ARG(rays->viewdirs != nullptr, "NerfMLP: viewdirs is NULL");
         DirBiasParams dp;
@@ -398,6 +456,7 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
         dp.deg = lv.deg;
         dp.E = lv.E;
         dp.out = raybias;
+        ProfScope ps(&m->prof, NLR_K_DIRBIAS, st);
         if ((rc = nlr_launch_dirbias(dp, st))) return rc;
     }
     MlpParams P;
@@ -434,6 +493,7 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     P.rgb = rgb;
     P.sem = sem;
     P.inten = (lv.use_int && inten) ? inten : nullptr;
+    ProfScope ps(&m->prof, NLR_K_MLP, st);
     return nlr_launch_mlp(P, lv.W, lv.WB, lv.HT, lv.view_f32, st);
 }
 
@@ -489,8 +549,12 @@ extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t 
         const float tf = cfg->train_frac;
         const float anneal = m->anneal_slope > 0 ? (float)(((double)m->anneal_slope * tf) / (((double)m->anneal_slope - 1.0) * tf + 1.0)) : 1.0f;
         const float *jit = cfg->rand_jitter[l];
-        int rc = nlr_launch_resample(prev_s, prev_w, n_prev, dilation, anneal, m->resample_padding, S, jit ? lv.u_rand : lv.u_det,
+        int rc;
+        {
+            ProfScope ps(&m->prof, NLR_K_RESAMPLE, st);
+            rc = nlr_launch_resample(prev_s, prev_w, n_prev, dilation, anneal, m->resample_padding, S, jit ? lv.u_rand : lv.u_det,
                                      jit, lv.max_jitter, rays->near, rays->far, m->power_lambda, N, sdist, tdist, st);
+        }
         if (rc) return rc;
         float *feat = nullptr, *rb = nullptr, *rgb = nullptr, *sem = nullptr, *inten = nullptr;
         if (!lv.is_prop) {
@@ -502,9 +566,12 @@ extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t 
         }
         rc = run_mlp_level(m, lv, rays, tdist, N, n, mloops, cfg->rand_deg[l], feat, rb, density, rgb, sem, inten, nullptr, st);
         if (rc) return rc;
-        rc = nlr_composite_level(density, tdist, rays->directions, last ? rgb : nullptr, last ? sem : nullptr, last ? inten : nullptr,
-                                 rays->far, rays->origins, N, S, lv.K, (int)m->opaque, m->bg, last ? (int)cfg->compute_extras : 0,
-                                 last ? cfg->scale_factor : 0.0f, weights, last ? out : nullptr, ho.depth, st);
+        {
+            ProfScope ps(&m->prof, NLR_K_COMPOSITE, st);
+            rc = nlr_composite_level(density, tdist, rays->directions, last ? rgb : nullptr, last ? sem : nullptr, last ? inten : nullptr,
+                                     rays->far, rays->origins, N, S, lv.K, (int)m->opaque, m->bg, last ? (int)cfg->compute_extras : 0,
+                                     last ? cfg->scale_factor : 0.0f, weights, last ? out : nullptr, ho.depth, st);
+        }
         if (rc) return rc;
         prev_s = sdist;
         prev_w = weights;

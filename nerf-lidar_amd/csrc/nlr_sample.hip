@@ -325,6 +325,6 @@ extern "C" int nlr_resample_level(const float *prev_sdist, const float *prev_wei
     NLR_HIP(hipStreamSynchronize(st));  // uh is a stack buffer
     int rc = nlr_launch_resample(prev_sdist, prev_weights, n_prev, dilation, anneal, resample_padding, num_samples, u_dev,
                                  rand_jitter, mj, near, far, power_lambda, N, sdist, tdist, st);
-    hipFreeAsync(u_dev, st);
+    (void)hipFreeAsync(u_dev, st);
     return rc;
 }

@@ -72,19 +72,25 @@ def synth_state_dict(mc: ModelConfig, seed: int = 0, table_std: float = 1e-4,
 
     table_std=1e-4 is the reference init (grid.py:101): with it every ray composites as uniform
     fog, which exercises little.  trained_like=True is SURVEY 8d's second weight set: tables
-    U(-1,1) and a few heads rescaled so that the random scene has empty space, opaque surfaces
+    U(-1,1) * 2^(-level/2) (fine levels carry less amplitude, as the reference's hash-decay
+    regulariser enforces, ZI/models.py:203-223; with full-amplitude white noise at resolution 8192 a
+    1-ulp change of a coordinate moves a feature by 5e-4, which measures libm differences, not the
+    renderer) and a few heads rescaled so that the random scene has empty space, opaque surfaces
     (density up to a few hundred), rays that reach the opaque background, and >10 distinct
     semantic labels per sweep:
       density_layer.2 (NerfMLP, all rows) x8, row 0 (raw density) x1500 in every MLP with its
-      bias shifted by -100, sem_layer.2.weight x8.
+      bias shifted by -40, sem_layer.2.weight x8.
     """
     if trained_like:
         table_std = 1.0
     sd: Dict[str, np.ndarray] = {}
     for prefix, cfg in mlp_names(mc):
         offsets, sizes, _ = grid_layout(cfg)
-        sd[f"{prefix}.encoder.embeddings"] = synth.table_init(
-            seed, f"{prefix}.encoder.embeddings", int(offsets[-1]), cfg.grid_level_dim, table_std)
+        table = synth.table_init(seed, f"{prefix}.encoder.embeddings", int(offsets[-1]), cfg.grid_level_dim, table_std)
+        if trained_like:
+            for l in range(len(offsets) - 1):
+                table[offsets[l]:offsets[l + 1]] *= np.float32(2.0 ** (-0.5 * l))
+        sd[f"{prefix}.encoder.embeddings"] = table
         sd[f"{prefix}.encoder.offsets"] = offsets
         sd[f"{prefix}.encoder.grid_sizes"] = sizes
         for name, (o, i), kaiming in mlp_param_shapes(cfg):
@@ -95,7 +101,7 @@ def synth_state_dict(mc: ModelConfig, seed: int = 0, table_std: float = 1e-4,
                     w[0] *= np.float32(1500.0 / 8.0)
                 else:
                     w[0] *= np.float32(1500.0)
-                b[0] += np.float32(-100.0)
+                b[0] += np.float32(-40.0)
             if trained_like and name == "sem_layer.2":
                 w = w * np.float32(8.0)
             sd[f"{prefix}.{name}.weight"] = np.ascontiguousarray(w, np.float32)

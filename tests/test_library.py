@@ -111,3 +111,39 @@ def test_azimuth_sector_partition():
     np.testing.assert_array_equal(img.reshape(-1, 3), b["directions"])
     # viewdirs keep the full-sweep Frobenius norm (quirk), so a sector renders identically to the full sweep
     np.testing.assert_array_equal(parts[1][0]["viewdirs"][0], b["viewdirs"][7])
+
+
+def _shard_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    from nerflidar_hip import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W = 4, 22  # W not divisible by world -> padded columns
+    full = nlidar.synthetic_sweep(width=W, seed=1, beams=nlidar.LIDAR_ANGLES[:H])
+
+    def fake_render(b):  # deterministic per-ray function standing in for the HIP renderer
+        d, o = b["directions"], b["origins"]
+        depth = (d * torch.tensor([1.0, 2.0, 3.0])).sum(-1) + o[:, 0]
+        return dict(depth=depth, intensity=depth * 0.5, acc=torch.ones_like(depth), rgb=d.abs(),
+                    labels=(depth.abs() * 7).to(torch.int32) % 19)
+
+    img = sharding.render_sweep_sharded(fake_render, full, H, W, "cpu")
+    one = sharding.pack_tile(fake_render({k: torch.from_numpy(v) for k, v in full.items()}), H, W)
+    assert img.shape == (H, W, 7)
+    assert torch.equal(img, one), "gathered range image differs from the single-process image"
+    assert torch.equal(sharding.unpack_image(img)["labels"], one[..., 6].to(torch.int32))
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("1")
+
+
+def test_sharded_sweep_world2_gloo(tmp_path):
+    """N>1 path on CPU: azimuth-sector partition + ONE all-gather reassembles the one-process image bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
