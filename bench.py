@@ -35,6 +35,18 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFM
 KNAMES = ["resample", "prop", "encode", "dirbias", "mlp", "composite"]
 
 
+def host_cores():
+    """CPU share of this process: affinity, capped by the cgroup quota, and by 16 (the one-GPU box's share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(mc, sd, batch_np, n_rays, threads):
     """The oracle (a port: PyTorch-CPU restatement pinned on reference fixtures) timed on this host's cores."""
     from oracle import nlr_oracle as orc
@@ -155,7 +167,7 @@ def main():
                          "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = len(os.sched_getaffinity(0))
+            threads = host_cores()
             out["cpu_baseline"] = cpu_baseline(mc, sd, sec, args.cpu_rays, threads)
         print(json.dumps(out))
     if world > 1:

@@ -243,33 +243,43 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
 // per-ray bias of view layers 0 and 1: b_l + W_l[:, dir columns] . pos_enc(viewdir)
 // ---------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) nlr_dirbias_kernel(DirBiasParams P) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.N * P.W) return;
-    const uint32_t ray = t / P.W, j = t - ray * P.W;
-    float e[3 + 6 * 8];
-    const float v[3] = {P.viewdirs[(size_t)ray * 3], P.viewdirs[(size_t)ray * 3 + 1], P.viewdirs[(size_t)ray * 3 + 2]};
+// One 64-thread workgroup per ray: the 3+6*deg encoding is computed once into LDS, then the W outputs of both
+// layers are strided over the lanes (weights are read row-contiguously, 27 floats per row).
+__global__ void __launch_bounds__(64) nlr_dirbias_kernel(DirBiasParams P) {
+    __shared__ float e[64];
+    const uint32_t ray = blockIdx.x;
+    const int lane = threadIdx.x;
     // coord.py:199-210: [x, sin(2^k x), sin(2^k x + pi/2)], k-major
-    for (int c = 0; c < 3; ++c) e[c] = v[c];
-    for (uint32_t k = 0; k < P.deg; ++k)
-        for (int c = 0; c < 3; ++c) {
-            const float sx = v[c] * (float)(1u << k);
-            e[3 + k * 3 + c] = sinf(sx);
-            e[3 + 3 * P.deg + k * 3 + c] = sinf(sx + 1.57079637050628662f);
+    if (lane < (int)P.E) {
+        float val;
+        if (lane < 3) {
+            val = P.viewdirs[(size_t)ray * 3 + lane];
+        } else {
+            const int q = lane - 3;
+            const int half = q >= (int)(3 * P.deg);
+            const int r = half ? q - 3 * P.deg : q;
+            const int k = r / 3, c = r - 3 * k;
+            const float sx = P.viewdirs[(size_t)ray * 3 + c] * (float)(1u << k);
+            val = half ? sinf(sx + 1.57079637050628662f) : sinf(sx);
         }
-    float a0 = P.b0[j], a1 = P.b1[j];
-    for (uint32_t i = 0; i < P.E; ++i) {
-        a0 = fmaf(P.wd0[(size_t)j * P.E + i], e[i], a0);
-        a1 = fmaf(P.wd1[(size_t)j * P.E + i], e[i], a1);
+        e[lane] = val;
     }
-    P.out[((size_t)ray * 2 + 0) * P.W + j] = a0;
-    P.out[((size_t)ray * 2 + 1) * P.W + j] = a1;
+    __syncthreads();
+    for (uint32_t j = lane; j < P.W; j += 64) {
+        float a0 = P.b0[j], a1 = P.b1[j];
+        const float *w0 = P.wd0 + (size_t)j * P.E, *w1 = P.wd1 + (size_t)j * P.E;
+        for (uint32_t i = 0; i < P.E; ++i) {
+            a0 = fmaf(w0[i], e[i], a0);
+            a1 = fmaf(w1[i], e[i], a1);
+        }
+        P.out[((size_t)ray * 2 + 0) * P.W + j] = a0;
+        P.out[((size_t)ray * 2 + 1) * P.W + j] = a1;
+    }
 }
 
 int nlr_launch_dirbias(const DirBiasParams &P, hipStream_t st) {
-    NLR_CHECK_ARG(P.deg <= 8, "deg_view %u > 8", P.deg);
-    const uint32_t T = P.N * P.W;
-    hipLaunchKernelGGL(nlr_dirbias_kernel, dim3((T + 255) / 256), dim3(256), 0, st, P);
+    NLR_CHECK_ARG(P.E <= 64, "dir encoding size %u > 64 (deg_view too large)", P.E);
+    hipLaunchKernelGGL(nlr_dirbias_kernel, dim3(P.N), dim3(64), 0, st, P);
     NLR_LAUNCH_CHECK("nlr_dirbias_kernel");
     return NLR_OK;
 }

@@ -135,8 +135,9 @@ def test_resample_with_dilation(name, S):
     ref_s = orc.sample_intervals(tdil, logits, S, (0., 1.))
     _, s_to_t = orc.construct_ray_warps(T(near)[:, None], T(far)[:, None], -1.5)
     # inverse-CDF interpolation divides by bin mass: 1e-7 differences in the CDF are amplified in low-mass bins
-    np.testing.assert_allclose(sd, ref_s.numpy(), atol=2e-5, rtol=0)
-    np.testing.assert_allclose(td, s_to_t(ref_s).numpy(), atol=2e-5, rtol=1e-4)
+    assert np.abs(sd - ref_s.numpy()).mean() <= 1e-6
+    np.testing.assert_allclose(sd, ref_s.numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(td, s_to_t(ref_s).numpy(), atol=1e-4, rtol=1e-4)
     assert (np.diff(sd, axis=-1) >= 0).all() and sd.min() >= 0 and sd.max() <= 1
 
 
