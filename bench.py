@@ -153,8 +153,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (sampling, hash grid, density/semantic/intensity layers on f32 MFMA) + bf16 MFMA (view MLP)"
-                     if args.precision == _lib.PREC_MIXED else "f32",
+            "dtype": {_lib.PREC_F32: "f32 (f32 MFMA everywhere)",
+                      _lib.PREC_MIXED: "f32 (sampling, hash grid, density/semantic/intensity layers on f32 MFMA) + bf16 MFMA (view MLP)",
+                      _lib.PREC_FAST: "f32 (sampling, hash grid) + split-bf16 x3 MFMA (density/semantic/intensity) + bf16 MFMA (view MLP)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: nuScenes 32-beam sweep, 32x1024 rays per GPU, samples (64,64,128), "
                                    "8x256 NerfMLP + semantic + intensity heads, full-size fp32 hash tables",

@@ -55,13 +55,13 @@ struct LevelModel {
     float p_b2 = 0.0f;
     // NerfMLP (matrix cores)
     uint32_t W = 0, WB = 0, D = 0, HT = 0, K = 0, int_row = 0xffffffffu, deg = 0, E = 0;
-    bool use_int = false, view_f32 = false;
+    bool use_int = false;
+    uint32_t prec = NLR_PREC_MIXED;
+    void *tape = nullptr;
+    uint32_t tape_chunks = 0;
     float rgb_premul = 1.0f, rgb_bias = 0.0f, rgb_padding = 0.001f;
-    void *w_d0 = nullptr, *w_d2 = nullptr, *w_h1 = nullptr, *w_h2 = nullptr;
     float *b_d0 = nullptr, *b_d2 = nullptr, *b_h1 = nullptr, *b_h2 = nullptr;
-    void *w_v0 = nullptr, *w_v1a = nullptr, *w_v1b = nullptr, *w_vl = nullptr, *w_rgb = nullptr;
     float *b_vl = nullptr, *b_rgb = nullptr;
-    size_t vl_stride = 0;
     float *wd0 = nullptr, *wd1 = nullptr, *b0 = nullptr, *b1 = nullptr;  // dir-encoding columns + biases of layers 0/1
     float *u_det = nullptr, *u_rand = nullptr;                            // sample positions [S]
     float max_jitter = 0.0f;
@@ -136,17 +136,44 @@ static std::vector<uint16_t> pack_bf16(const Mat &w, uint32_t OT, uint32_t KG) {
     return p;
 }
 
-static int upload_packed(NlrModel *m, const Mat &w, uint32_t out_pad, uint32_t in_pad, bool f32, void **out, size_t *elems16 = nullptr) {
-    const uint32_t OT = out_pad / 32;
-    if (f32) {
-        auto p = pack_f32(w, OT, in_pad / 8);
-        if (elems16) *elems16 = p.size() / 4;
-        return dev_upload(m, p.data(), p.size() * sizeof(float), out);
-    }
-    auto p = pack_bf16(w, OT, in_pad / 16);
-    if (elems16) *elems16 = p.size() / 8;
-    return dev_upload(m, p.data(), p.size() * sizeof(uint16_t), out);
+// split-bf16 fragments: for every (kstep, otile) the hi fragment then the lo fragment (W = hi + lo)
+static std::vector<uint16_t> pack_x3(const Mat &w, uint32_t OT, uint32_t KG) {
+    std::vector<uint16_t> p((size_t)KG * OT * 2 * 64 * 8);
+    for (uint32_t g = 0; g < KG; ++g)
+        for (uint32_t o = 0; o < OT; ++o)
+            for (uint32_t lane = 0; lane < 64; ++lane)
+                for (uint32_t j = 0; j < 8; ++j) {
+                    const float v = w.get(32 * o + (lane & 31), 16 * g + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3));
+                    const uint16_t hi = f32_to_bf16(v);
+                    uint32_t hb = (uint32_t)hi << 16;
+                    float hf;
+                    memcpy(&hf, &hb, 4);
+                    const size_t base = (((size_t)g * OT + o) * 2) * 64 * 8;
+                    p[base + (size_t)lane * 8 + j] = hi;
+                    p[base + 64 * 8 + (size_t)lane * 8 + j] = f32_to_bf16(v - hf);
+                }
+    return p;
 }
+
+// The weight tape: GEMMs appended in the order nlr_mlp_kernel consumes them, each padded to whole 16 KiB chunks.
+enum { TAPE_F32 = 0, TAPE_BF16 = 1, TAPE_X3 = 2 };
+struct TapeBuilder {
+    std::vector<uint8_t> bytes;
+    void add(const Mat &w, uint32_t out_pad, uint32_t in_pad, int kind) {
+        const uint32_t OT = out_pad / 32;
+        if (kind == TAPE_F32) {
+            auto p = pack_f32(w, OT, in_pad / 8);
+            bytes.insert(bytes.end(), (const uint8_t *)p.data(), (const uint8_t *)(p.data() + p.size()));
+        } else if (kind == TAPE_BF16) {
+            auto p = pack_bf16(w, OT, (in_pad + 15) / 16);
+            bytes.insert(bytes.end(), (const uint8_t *)p.data(), (const uint8_t *)(p.data() + p.size()));
+        } else {
+            auto p = pack_x3(w, OT, (in_pad + 15) / 16);
+            bytes.insert(bytes.end(), (const uint8_t *)p.data(), (const uint8_t *)(p.data() + p.size()));
+        }
+        bytes.resize((bytes.size() + 16383) / 16384 * 16384, 0);
+    }
+};
 
 static int upload_bias(NlrModel *m, const float *b, uint32_t n, uint32_t pad, float **out) {
     std::vector<float> v(pad, 0.0f);
@@ -200,8 +227,6 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     lv.rgb_premul = d.rgb_premultiplier;
     lv.rgb_bias = d.rgb_bias;
     lv.rgb_padding = d.rgb_padding;
-    lv.view_f32 = (prec == NLR_PREC_F32);
-    if (prec == NLR_PREC_FAST) NLR_FAIL(NLR_ERR_UNSUPPORTED, "NLR_PREC_FAST (split-bf16 heads) is not built yet");
     if (lv.D < 2 || d.skip_layer_dir != 0 || lv.D > NLR_MAX_VIEW_DEPTH)
         NLR_FAIL(NLR_ERR_UNSUPPORTED, "view MLP: fused path needs net_depth_viewdirs in [2,%d] and skip_layer_dir = 0 (got %u, %u)",
                  NLR_MAX_VIEW_DEPTH, lv.D, d.skip_layer_dir);
@@ -217,10 +242,14 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     NLR_CHECK_ARG(lv.K + (lv.use_int ? 1 : 0) <= 32, "class_num %u (+intensity) exceeds one 32-row output tile", lv.K);
 
     const uint32_t Fpad = ((lv.F + 7) / 8) * 8;
+    lv.prec = prec;
+    const int crit = (prec == NLR_PREC_FAST) ? TAPE_X3 : TAPE_F32;   // density trunk + heads
+    const int view = (prec == NLR_PREC_F32) ? TAPE_F32 : TAPE_BF16;  // view MLP
+    TapeBuilder tb;
     // density trunk
-    if ((rc = upload_packed(m, mat_from(d.density0, 0, lv.F), 64, Fpad, true, &lv.w_d0))) return rc;
+    tb.add(mat_from(d.density0, 0, lv.F), 64, Fpad, crit);
     if ((rc = upload_bias(m, d.density0.bias, 64, 64, &lv.b_d0))) return rc;
-    if ((rc = upload_packed(m, mat_from(d.density2, 0, 64), lv.WB, 64, true, &lv.w_d2))) return rc;
+    tb.add(mat_from(d.density2, 0, 64), lv.WB, 64, crit);
     if ((rc = upload_bias(m, d.density2.bias, lv.WB, lv.WB, &lv.b_d2))) return rc;
     // heads: [sem0 ; int0] stacked, then a block-diagonal [sem2 | 0 ; 0 | int2] into one 32-row tile
     if (lv.HT) {
@@ -252,19 +281,18 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
             for (uint32_t c = 0; c < 64; ++c) h2.at(lv.int_row, r0 + c) = d.int2.weight[c];
             b2[lv.int_row] = d.int2.bias[0];
         }
-        if ((rc = upload_packed(m, h1, HH, lv.WB, true, &lv.w_h1))) return rc;
+        tb.add(h1, HH, lv.WB, crit);
         if ((rc = upload_bias(m, b1.data(), HH, HH, &lv.b_h1))) return rc;
-        if ((rc = upload_packed(m, h2, 32, HH, true, &lv.w_h2))) return rc;
+        tb.add(h2, 32, HH, crit);
         if ((rc = upload_bias(m, b2.data(), 32, 32, &lv.b_h2))) return rc;
     }
     // view MLP.  Input of layer 0 = [bottleneck (WB) | dir_enc (E)]; of layer 1 = [x (W) | bottleneck | dir_enc]
     const uint32_t in0 = lv.WB + lv.E, in1 = lv.W + in0;
     if ((rc = check_linear(d.view[0], lv.W, in0, "lin_second_stage_0"))) return rc;
     if ((rc = check_linear(d.view[1], lv.W, in1, "lin_second_stage_1"))) return rc;
-    const bool vf = lv.view_f32;
-    if ((rc = upload_packed(m, mat_from(d.view[0], 0, lv.WB), lv.W, lv.WB, vf, &lv.w_v0))) return rc;
-    if ((rc = upload_packed(m, mat_from(d.view[1], 0, lv.W), lv.W, lv.W, vf, &lv.w_v1a))) return rc;
-    if ((rc = upload_packed(m, mat_from(d.view[1], lv.W, lv.WB), lv.W, lv.WB, vf, &lv.w_v1b))) return rc;
+    tb.add(mat_from(d.view[0], 0, lv.WB), lv.W, lv.WB, view);
+    tb.add(mat_from(d.view[1], 0, lv.W), lv.W, lv.W, view);
+    tb.add(mat_from(d.view[1], lv.W, lv.WB), lv.W, lv.WB, view);
     {
         Mat e0 = mat_from(d.view[0], lv.WB, lv.E), e1 = mat_from(d.view[1], lv.W + lv.WB, lv.E);
         if ((rc = dev_upload(m, e0.a.data(), e0.a.size() * 4, (void **)&lv.wd0))) return rc;
@@ -272,33 +300,22 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
         if ((rc = dev_upload(m, d.view[0].bias, lv.W * 4, (void **)&lv.b0))) return rc;
         if ((rc = dev_upload(m, d.view[1].bias, lv.W * 4, (void **)&lv.b1))) return rc;
     }
-    if (lv.D > 2) {
-        std::vector<uint8_t> blob;
-        std::vector<float> bl((size_t)(lv.D - 2) * lv.W);
-        size_t per = 0;
+    {
+        std::vector<float> bl((size_t)(lv.D > 2 ? lv.D - 2 : 1) * lv.W, 0.0f);
         for (uint32_t l = 2; l < lv.D; ++l) {
             char nm[64];
             snprintf(nm, sizeof(nm), "lin_second_stage_%u", l);
             if ((rc = check_linear(d.view[l], lv.W, lv.W, nm))) return rc;
-            Mat wl = mat_from(d.view[l], 0, lv.W);
-            if (vf) {
-                auto p = pack_f32(wl, lv.W / 32, lv.W / 8);
-                per = p.size() / 4;
-                blob.insert(blob.end(), (uint8_t *)p.data(), (uint8_t *)(p.data() + p.size()));
-            } else {
-                auto p = pack_bf16(wl, lv.W / 32, lv.W / 16);
-                per = p.size() / 8;
-                blob.insert(blob.end(), (uint8_t *)p.data(), (uint8_t *)(p.data() + p.size()));
-            }
+            tb.add(mat_from(d.view[l], 0, lv.W), lv.W, lv.W, view);
             memcpy(&bl[(size_t)(l - 2) * lv.W], d.view[l].bias, lv.W * 4);
         }
-        lv.vl_stride = per;
-        if ((rc = dev_upload(m, blob.data(), blob.size(), &lv.w_vl))) return rc;
         if ((rc = dev_upload(m, bl.data(), bl.size() * 4, (void **)&lv.b_vl))) return rc;
     }
     if ((rc = check_linear(d.rgb_layer, 3, lv.W, "rgb_layer"))) return rc;
-    if ((rc = upload_packed(m, mat_from(d.rgb_layer, 0, lv.W), 32, lv.W, vf, &lv.w_rgb))) return rc;
+    tb.add(mat_from(d.rgb_layer, 0, lv.W), 32, lv.W, view);
     if ((rc = upload_bias(m, d.rgb_layer.bias, 3, 32, &lv.b_rgb))) return rc;
+    lv.tape_chunks = (uint32_t)(tb.bytes.size() / 16384);
+    if ((rc = dev_upload(m, tb.bytes.data(), tb.bytes.size(), &lv.tape))) return rc;
     return NLR_OK;
 }
 
@@ -465,24 +482,16 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     P.M = N * lv.S;
     P.S = lv.S;
     P.F = lv.F;
-    P.w_d0 = (const f32x4 *)lv.w_d0;
-    P.w_d2 = (const f32x4 *)lv.w_d2;
-    P.w_h1 = (const f32x4 *)lv.w_h1;
-    P.w_h2 = (const f32x4 *)lv.w_h2;
+    P.tape = (const uint4 *)lv.tape;
+    P.tape_chunks = lv.tape_chunks;
     P.b_d0 = lv.b_d0;
     P.b_d2 = lv.b_d2;
     P.b_h1 = lv.b_h1;
     P.b_h2 = lv.b_h2;
-    P.w_v0 = lv.w_v0;
-    P.w_v1a = lv.w_v1a;
-    P.w_v1b = lv.w_v1b;
-    P.w_vl = lv.w_vl;
-    P.w_rgb = lv.w_rgb;
     P.b_vl = lv.b_vl;
     P.b_rgb = lv.b_rgb;
     P.raybias = raybias;
     P.depth = lv.D;
-    P.vl_stride = lv.vl_stride;
     P.K = sem ? lv.K : 0;
     P.int_row = lv.int_row;
     P.density_bias = lv.density_bias;
@@ -494,7 +503,7 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     P.sem = sem;
     P.inten = (lv.use_int && inten) ? inten : nullptr;
     ProfScope ps(&m->prof, NLR_K_MLP, st);
-    return nlr_launch_mlp(P, lv.W, lv.WB, lv.HT, lv.view_f32, st);
+    return nlr_launch_mlp(P, lv.W, lv.WB, lv.HT, lv.prec, st);
 }
 
 extern "C" int nlr_mlp_level(const NlrModel *m, uint32_t level, const NlrRays *rays, const float *tdist, uint32_t N,

@@ -35,16 +35,15 @@ struct TileH {
 struct MlpParams {
     const float *feat;      // [M, F] f32
     uint32_t M, S, F;       // samples, samples per ray, feature count
-    // packed f32 fragments: [kgroup][otile][lane] float4
-    const f32x4 *w_d0, *w_d2, *w_h1, *w_h2;
+    // Weight tape: every GEMM's A fragments (1 KiB each: 64 lanes x 16 B) in consumption order
+    // D0, D2, [H1, H2], V0, V1a, V1b, V2..V(D-1), RGB; each GEMM padded to whole 16 KiB chunks.
+    const uint4 *tape;
+    uint32_t tape_chunks;
     const float *b_d0, *b_d2, *b_h1, *b_h2;  // padded to 32*OT
-    // view MLP: packed fragments (bf16x8 or float4 depending on precision)
-    const void *w_v0, *w_v1a, *w_v1b, *w_vl, *w_rgb;  // w_vl: layers 2..D-1 back to back
     const float *b_vl;      // [(D-2), W]
     const float *b_rgb;     // [32]
     const float *raybias;   // [N, 2, W] per-ray bias of layers 0 and 1 (bias + dir_enc columns)
     uint32_t depth;         // net_depth_viewdirs
-    size_t vl_stride;       // elements (16 B units) between consecutive packed hidden layers
     uint32_t K, int_row;    // class_num (0 = no semantic head), row of the intensity output (or 0xffffffff)
     float density_bias, rgb_premul, rgb_bias, rgb_padding;
     float *density, *rgb, *sem, *inten;  // outputs: [M], [M,3], [M,K], [M]
@@ -67,5 +66,5 @@ int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights
 int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1, const float *b1, const float *w2, float b2,
                     float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st);
 int nlr_launch_dirbias(const DirBiasParams &P, hipStream_t st);
-int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, bool view_f32, hipStream_t st);
+int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, hipStream_t st);
 int nlr_launch_composite(const CompositeParams &P, hipStream_t st);

@@ -38,43 +38,115 @@ __device__ __forceinline__ void nlr_acc_bias(f32x16 (&acc)[OT], const float *__r
         }
 }
 
-// acc[o] += W[o-tile, :] . in   on the exact-f32 MFMA.  KG = number of 8-feature k-groups.
+// ---- weight tape: global -> registers -> LDS (double buffered), shared by the 4 waves of a workgroup ----------
+// A chunk is 16 KiB = 16 fragments of 1 KiB.  While the waves run the MFMAs of chunk c out of LDS buffer c&1, the
+// 256 threads have the 4 x 16 B global loads of chunk c+1 in flight; they land in the other buffer after the MFMAs,
+// one __syncthreads() per chunk.  Every wave needs every fragment (each wave owns 32 samples and all output
+// features), so staging through LDS cuts the L2 -> CU weight traffic 4x against per-wave global loads and puts the
+// fragment reads on ds_read_b128 (64-cycle latency) instead of L2 (500+ cycles at one wave per SIMD).
+#define NLR_CHUNK_SLOTS 1024  // uint4 slots per chunk
+struct Tape {
+    const uint4 *__restrict__ base;
+    uint4 *lds;  // [2][NLR_CHUNK_SLOTS]
+    uint4 nxt[4];
+    int cur, total, tid;
+    __device__ __forceinline__ void load(int c) {
+        const uint4 *p = base + (size_t)c * NLR_CHUNK_SLOTS + tid;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxt[r] = p[r * 256];
+    }
+    __device__ __forceinline__ void store(int c) {
+        uint4 *q = lds + (c & 1) * NLR_CHUNK_SLOTS + tid;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r * 256] = nxt[r];
+    }
+    __device__ __forceinline__ void prologue() {
+        cur = 0;
+        load(0);
+        store(0);
+        __syncthreads();
+    }
+    __device__ __forceinline__ void begin() {
+        if (cur + 1 < total) load(cur + 1);
+    }
+    __device__ __forceinline__ void end() {
+        if (cur + 1 < total) store(cur + 1);
+        __syncthreads();
+        ++cur;
+    }
+    template <typename T>
+    __device__ __forceinline__ T frag(int f, int lane) const {
+        return *reinterpret_cast<const T *>(lds + (cur & 1) * NLR_CHUNK_SLOTS + f * 64 + lane);
+    }
+};
+
+// acc[o] += W[o-tile, :] . in   on the exact-f32 MFMA.  KG = number of 8-feature k-groups (one fragment = 4 k-steps).
 template <int OT, int KG, int KT>
-__device__ __forceinline__ void nlr_gemm_f32(f32x16 (&acc)[OT], const f32x16 (&in)[KT], const f32x4 *__restrict__ w, int lane) {
+__device__ __forceinline__ void nlr_gemm_f32(f32x16 (&acc)[OT], const f32x16 (&in)[KT], Tape &tp, int lane) {
     static_assert(KG <= KT * 4, "k-groups exceed the input tiles");
-    f32x4 a[2][OT];
+    constexpr int NF = KG * OT, NCH = (NF + 15) / 16;
 #pragma unroll
-    for (int o = 0; o < OT; ++o) a[0][o] = w[o * 64 + lane];
+    for (int ch = 0; ch < NCH; ++ch) {
+        tp.begin();
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-        if (g + 1 < KG) {
+        for (int f = 0; f < 16; ++f) {
+            const int idx = ch * 16 + f;
+            if (idx < NF) {
+                const int g = idx / OT, o = idx % OT;
+                const f32x4 a = tp.frag<f32x4>(f, lane);
 #pragma unroll
-            for (int o = 0; o < OT; ++o) a[(g + 1) & 1][o] = w[((g + 1) * OT + o) * 64 + lane];
+                for (int e = 0; e < 4; ++e)
+                    acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], in[g >> 2][(g & 3) * 4 + e], acc[o], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int o = 0; o < OT; ++o)
-                acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][o][e], in[g >> 2][(g & 3) * 4 + e], acc[o], 0, 0, 0);
+        tp.end();
     }
 }
 
 // acc[o] += W[o-tile, :] . in   on the bf16 MFMA.  KG = number of 16-feature k-steps (= 2 per input tile).
 template <int OT, int KG, int KT>
-__device__ __forceinline__ void nlr_gemm_bf16(f32x16 (&acc)[OT], const TileH (&in)[KT], const bf16x8 *__restrict__ w, int lane) {
+__device__ __forceinline__ void nlr_gemm_bf16(f32x16 (&acc)[OT], const TileH (&in)[KT], Tape &tp, int lane) {
     static_assert(KG <= KT * 2, "k-steps exceed the input tiles");
-    bf16x8 a[2][OT];
+    constexpr int NF = KG * OT, NCH = (NF + 15) / 16;
 #pragma unroll
-    for (int o = 0; o < OT; ++o) a[0][o] = w[o * 64 + lane];
+    for (int ch = 0; ch < NCH; ++ch) {
+        tp.begin();
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-        if (g + 1 < KG) {
-#pragma unroll
-            for (int o = 0; o < OT; ++o) a[(g + 1) & 1][o] = w[((g + 1) * OT + o) * 64 + lane];
+        for (int f = 0; f < 16; ++f) {
+            const int idx = ch * 16 + f;
+            if (idx < NF) {
+                const int g = idx / OT, o = idx % OT;
+                const bf16x8 a = tp.frag<bf16x8>(f, lane);
+                acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, in[g >> 1].f[g & 1], acc[o], 0, 0, 0);
+            }
         }
+        tp.end();
+    }
+}
+
+// Split-bf16 ("bf16x3"): W = Wh + Wl, x = xh + xl (each part bf16), W.x ~= Wh.xh + Wh.xl + Wl.xh with f32
+// accumulation: 16 mantissa bits per operand (relative error ~2^-16) at 3/16 of the exact-f32 MFMA cost.
+// Fragments come in (hi, lo) pairs.
+template <int OT, int KG, int KT>
+__device__ __forceinline__ void nlr_gemm_x3(f32x16 (&acc)[OT], const TileH (&inh)[KT], const TileH (&inl)[KT], Tape &tp, int lane) {
+    static_assert(KG <= KT * 2, "k-steps exceed the input tiles");
+    constexpr int NP = KG * OT, NCH = (NP + 7) / 8;
 #pragma unroll
-        for (int o = 0; o < OT; ++o)
-            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][o], in[g >> 1].f[g & 1], acc[o], 0, 0, 0);
+    for (int ch = 0; ch < NCH; ++ch) {
+        tp.begin();
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+            const int idx = ch * 8 + pr;
+            if (idx < NP) {
+                const int g = idx / OT, o = idx % OT;
+                const bf16x8 ah = tp.frag<bf16x8>(2 * pr, lane);
+                const bf16x8 al = tp.frag<bf16x8>(2 * pr + 1, lane);
+                acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, inh[g >> 1].f[g & 1], acc[o], 0, 0, 0);
+                acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, inl[g >> 1].f[g & 1], acc[o], 0, 0, 0);
+                acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, inh[g >> 1].f[g & 1], acc[o], 0, 0, 0);
+            }
+        }
+        tp.end();
     }
 }
 
@@ -91,6 +163,23 @@ __device__ __forceinline__ void nlr_pack(TileH (&dst)[T], const f32x16 (&src)[T]
             }
 }
 
+// hi = bf16(x), lo = bf16(x - hi)   (x - hi is exact in f32)
+template <int T, bool RELU>
+__device__ __forceinline__ void nlr_split(TileH (&hi)[T], TileH (&lo)[T], const f32x16 (&src)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = src[t][8 * s + j];
+                if (RELU) v = fmaxf(v, 0.0f);
+                const __bf16 h = (__bf16)v;
+                hi[t].f[s][j] = h;
+                lo[t].f[s][j] = (__bf16)(v - (float)h);
+            }
+}
+
 template <int T>
 __device__ __forceinline__ void nlr_relu(f32x16 (&x)[T]) {
 #pragma unroll
@@ -100,14 +189,25 @@ __device__ __forceinline__ void nlr_relu(f32x16 (&x)[T]) {
 }
 
 // WT = view width / 32, BT = bottleneck / 32, FG = ceil(F/8), HT = head hidden tiles (0, 2 or 4)
-template <int WT, int BT, int FG, int HT, bool VIEW_F32>
+// PREC: NLR_PREC_F32 (all f32), NLR_PREC_MIXED (trunk+heads f32, view bf16), NLR_PREC_FAST (trunk+heads bf16x3, view bf16)
+template <int WT, int BT, int FG, int HT, int PREC>
 __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
+    __shared__ __align__(16) uint4 lds_tape[2 * NLR_CHUNK_SLOTS];
+    constexpr bool VIEW_F32 = (PREC == NLR_PREC_F32);
+    constexpr bool X3 = (PREC == NLR_PREC_FAST);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, h = lane >> 5;
     const uint32_t sample = (blockIdx.x * 4 + wave) * 32 + col;
     const bool valid = sample < P.M;
     const uint32_t sc = valid ? sample : P.M - 1;
     constexpr int FT = (FG + 3) / 4;
+
+    Tape tp;
+    tp.base = P.tape;
+    tp.lds = lds_tape;
+    tp.total = (int)P.tape_chunks;
+    tp.tid = threadIdx.x;
+    tp.prologue();
 
     // ---- features -> accumulator-layout tiles (lane half h holds features 8q+4h..+3 of each group)
     f32x16 fin[FT];
@@ -126,28 +226,56 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
             for (int e = 0; e < 4; ++e) fin[g >> 2][(g & 3) * 4 + e] = v[e];
         }
     }
-    // ---- density_layer.0 : F -> 64, ReLU
-    f32x16 hid[2];
-    nlr_acc_bias<2>(hid, P.b_d0, h);
-    nlr_gemm_f32<2, FG, FT>(hid, fin, P.w_d0, lane);
-    nlr_relu<2>(hid);
-    // ---- density_layer.2 : 64 -> bottleneck (no activation); row 0 is the raw density
     f32x16 hb[BT];
-    nlr_acc_bias<BT>(hb, P.b_d2, h);
-    nlr_gemm_f32<BT, 8, 2>(hb, hid, P.w_d2, lane);
+    TileH hbh[VIEW_F32 ? 1 : BT];  // bf16 copy of the bottleneck for the view MLP (= hi part in FAST mode)
+    f32x16 lo[1];
+    if constexpr (!X3) {
+        // ---- density_layer.0 : F -> 64, ReLU
+        f32x16 hid[2];
+        nlr_acc_bias<2>(hid, P.b_d0, h);
+        nlr_gemm_f32<2, FG, FT>(hid, fin, tp, lane);
+        nlr_relu<2>(hid);
+        // ---- density_layer.2 : 64 -> bottleneck (no activation); row 0 is the raw density
+        nlr_acc_bias<BT>(hb, P.b_d2, h);
+        nlr_gemm_f32<BT, 8, 2>(hb, hid, tp, lane);
+        if constexpr (HT > 0) {
+            f32x16 hh[HT];
+            nlr_acc_bias<HT>(hh, P.b_h1, h);
+            nlr_gemm_f32<HT, BT * 4, BT>(hh, hb, tp, lane);
+            nlr_relu<HT>(hh);
+            nlr_acc_bias<1>(lo, P.b_h2, h);
+            nlr_gemm_f32<1, HT * 4, HT>(lo, hh, tp, lane);
+        }
+        if constexpr (!VIEW_F32) nlr_pack<BT, false>(hbh, hb);
+    } else {
+        constexpr int FK = (FG + 1) / 2;  // 16-feature k-steps covering the grid features
+        TileH fh[FT], fl[FT];
+        nlr_split<FT, false>(fh, fl, fin);
+        f32x16 hid[2];
+        nlr_acc_bias<2>(hid, P.b_d0, h);
+        nlr_gemm_x3<2, FK, FT>(hid, fh, fl, tp, lane);
+        TileH dh[2], dl[2];
+        nlr_split<2, true>(dh, dl, hid);
+        nlr_acc_bias<BT>(hb, P.b_d2, h);
+        nlr_gemm_x3<BT, 4, 2>(hb, dh, dl, tp, lane);
+        TileH hbl[BT];
+        nlr_split<BT, false>(hbh, hbl, hb);
+        if constexpr (HT > 0) {
+            f32x16 hh[HT];
+            nlr_acc_bias<HT>(hh, P.b_h1, h);
+            nlr_gemm_x3<HT, BT * 2, BT>(hh, hbh, hbl, tp, lane);
+            TileH qh[HT], ql[HT];
+            nlr_split<HT, true>(qh, ql, hh);
+            nlr_acc_bias<1>(lo, P.b_h2, h);
+            nlr_gemm_x3<1, HT * 2, HT>(lo, qh, ql, tp, lane);
+        }
+    }
     if (h == 0 && valid) {
         const float x = hb[0][0] + P.density_bias;
         P.density[sample] = x > 20.0f ? x : log1pf(expf(x));
     }
-    // ---- semantic / intensity heads: bottleneck -> 64 (+64) -> [K logits | intensity]
+    // ---- semantic / intensity outputs: rows [0,K) logits -> softmax, row int_row -> intensity
     if constexpr (HT > 0) {
-        f32x16 hh[HT];
-        nlr_acc_bias<HT>(hh, P.b_h1, h);
-        nlr_gemm_f32<HT, BT * 4, BT>(hh, hb, P.w_h1, lane);
-        nlr_relu<HT>(hh);
-        f32x16 lo[1];
-        nlr_acc_bias<1>(lo, P.b_h2, h);
-        nlr_gemm_f32<1, HT * 4, HT>(lo, hh, P.w_h2, lane);
         if (P.K > 0) {  // softmax over rows [0,K) of this column, split over the two lane halves
             float mx = -INFINITY;
 #pragma unroll
@@ -176,7 +304,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 if (nlr_row(r, h) == (int)P.int_row) P.inten[sample] = lo[0][r];
         }
     }
-    if (P.rgb == nullptr) return;  // density/semantic/intensity only
+    if (P.rgb == nullptr) return;  // density/semantic/intensity only (uniform for the whole grid)
 
     // ---- view MLP
     const uint32_t ray = sc / P.S;
@@ -185,49 +313,43 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     f32x16 acc[WT];
     f32x16 out1[1];
     if constexpr (!VIEW_F32) {
-        const bf16x8 *w_v0 = (const bf16x8 *)P.w_v0, *w_v1a = (const bf16x8 *)P.w_v1a, *w_v1b = (const bf16x8 *)P.w_v1b;
-        const bf16x8 *w_vl = (const bf16x8 *)P.w_vl, *w_rgb = (const bf16x8 *)P.w_rgb;
-        TileH hbh[BT];
-        nlr_pack<BT, false>(hbh, hb);
         nlr_acc_bias<WT>(acc, rb0, h);
-        nlr_gemm_bf16<WT, BT * 2, BT>(acc, hbh, w_v0, lane);
+        nlr_gemm_bf16<WT, BT * 2, BT>(acc, hbh, tp, lane);
         TileH x[WT];
         nlr_pack<WT, true>(x, acc);
         nlr_acc_bias<WT>(acc, rb1, h);
-        nlr_gemm_bf16<WT, WT * 2, WT>(acc, x, w_v1a, lane);
-        nlr_gemm_bf16<WT, BT * 2, BT>(acc, hbh, w_v1b, lane);
+        nlr_gemm_bf16<WT, WT * 2, WT>(acc, x, tp, lane);
+        nlr_gemm_bf16<WT, BT * 2, BT>(acc, hbh, tp, lane);
         nlr_pack<WT, true>(x, acc);
         for (uint32_t l = 2; l < P.depth; ++l) {
             nlr_acc_bias<WT>(acc, P.b_vl + (size_t)(l - 2) * (WT * 32), h);
-            nlr_gemm_bf16<WT, WT * 2, WT>(acc, x, w_vl + (size_t)(l - 2) * P.vl_stride, lane);
+            nlr_gemm_bf16<WT, WT * 2, WT>(acc, x, tp, lane);
             nlr_pack<WT, true>(x, acc);
         }
         nlr_acc_bias<1>(out1, P.b_rgb, h);
-        nlr_gemm_bf16<1, WT * 2, WT>(out1, x, w_rgb, lane);
+        nlr_gemm_bf16<1, WT * 2, WT>(out1, x, tp, lane);
     } else {
-        const f32x4 *w_v0 = (const f32x4 *)P.w_v0, *w_v1a = (const f32x4 *)P.w_v1a, *w_v1b = (const f32x4 *)P.w_v1b;
-        const f32x4 *w_vl = (const f32x4 *)P.w_vl, *w_rgb = (const f32x4 *)P.w_rgb;
         nlr_acc_bias<WT>(acc, rb0, h);
-        nlr_gemm_f32<WT, BT * 4, BT>(acc, hb, w_v0, lane);
+        nlr_gemm_f32<WT, BT * 4, BT>(acc, hb, tp, lane);
         f32x16 x[WT];
 #pragma unroll
         for (int t = 0; t < WT; ++t) x[t] = acc[t];
         nlr_relu<WT>(x);
         nlr_acc_bias<WT>(acc, rb1, h);
-        nlr_gemm_f32<WT, WT * 4, WT>(acc, x, w_v1a, lane);
-        nlr_gemm_f32<WT, BT * 4, BT>(acc, hb, w_v1b, lane);
+        nlr_gemm_f32<WT, WT * 4, WT>(acc, x, tp, lane);
+        nlr_gemm_f32<WT, BT * 4, BT>(acc, hb, tp, lane);
 #pragma unroll
         for (int t = 0; t < WT; ++t) x[t] = acc[t];
         nlr_relu<WT>(x);
         for (uint32_t l = 2; l < P.depth; ++l) {
             nlr_acc_bias<WT>(acc, P.b_vl + (size_t)(l - 2) * (WT * 32), h);
-            nlr_gemm_f32<WT, WT * 4, WT>(acc, x, w_vl + (size_t)(l - 2) * P.vl_stride, lane);
+            nlr_gemm_f32<WT, WT * 4, WT>(acc, x, tp, lane);
 #pragma unroll
             for (int t = 0; t < WT; ++t) x[t] = acc[t];
             nlr_relu<WT>(x);
         }
         nlr_acc_bias<1>(out1, P.b_rgb, h);
-        nlr_gemm_f32<1, WT * 4, WT>(out1, x, w_rgb, lane);
+        nlr_gemm_f32<1, WT * 4, WT>(out1, x, tp, lane);
     }
     if (h == 0 && valid) {
 #pragma unroll
@@ -285,16 +407,18 @@ int nlr_launch_dirbias(const DirBiasParams &P, hipStream_t st) {
 }
 
 // Supported shapes are instantiated explicitly; everything else is reported, not silently emulated.
-int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, bool view_f32, hipStream_t st) {
+int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, hipStream_t st) {
     NLR_CHECK_ARG(P.M > 0, "mlp: no samples");
+    NLR_CHECK_ARG(P.tape && P.tape_chunks > 0, "mlp: weight tape missing");
     const uint32_t FG = (P.F + 7) / 8;
     dim3 grid((P.M + 127) / 128), block(256);
-#define NLR_MLP(WT, BT, FGv, HTv)                                                                             \
-    do {                                                                                                      \
-        if (view_f32) hipLaunchKernelGGL((nlr_mlp_kernel<WT, BT, FGv, HTv, true>), grid, block, 0, st, P);   \
-        else hipLaunchKernelGGL((nlr_mlp_kernel<WT, BT, FGv, HTv, false>), grid, block, 0, st, P);           \
-        NLR_LAUNCH_CHECK("nlr_mlp_kernel");                                                                   \
-        return NLR_OK;                                                                                        \
+#define NLR_MLP(WT, BT, FGv, HTv)                                                                                      \
+    do {                                                                                                               \
+        if (prec == NLR_PREC_F32) hipLaunchKernelGGL((nlr_mlp_kernel<WT, BT, FGv, HTv, NLR_PREC_F32>), grid, block, 0, st, P);        \
+        else if (prec == NLR_PREC_MIXED) hipLaunchKernelGGL((nlr_mlp_kernel<WT, BT, FGv, HTv, NLR_PREC_MIXED>), grid, block, 0, st, P); \
+        else hipLaunchKernelGGL((nlr_mlp_kernel<WT, BT, FGv, HTv, NLR_PREC_FAST>), grid, block, 0, st, P);            \
+        NLR_LAUNCH_CHECK("nlr_mlp_kernel");                                                                            \
+        return NLR_OK;                                                                                                 \
     } while (0)
     if (WB == 256 && FG == 5) {
         if (W == 256 && HT == 4) NLR_MLP(8, 8, 5, 4);

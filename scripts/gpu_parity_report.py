@@ -18,7 +18,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "tests/golden/fwd_*.npz"))):
     sd = nweights.synth_state_dict(mc, seed=int(g["seed"]), trained_like=bool(g["trained_like"]))
     batch_np = nlidar.synthetic_sweep(width=int(g["width"]), seed=int(g["seed"]), beams=list(g["beams"]))
     batch = {k: torch.from_numpy(v).cuda() for k, v in batch_np.items()}
-    for prec in (0, 1):
+    for prec in (0, 1, 2):
         model = Model(mc, sd, precision=prec)
         rend, hist = model(False, batch, 1.0, True)
         print(os.path.basename(path), "precision", prec)

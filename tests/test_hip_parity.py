@@ -212,7 +212,7 @@ def _model(g, precision):
 
 
 @pytest.mark.parametrize("name", _names("mlp_"))
-@pytest.mark.parametrize("precision", [_lib.PREC_F32, _lib.PREC_MIXED])
+@pytest.mark.parametrize("precision", [_lib.PREC_F32, _lib.PREC_MIXED, _lib.PREC_FAST])
 def test_mlp_level(name, precision):
     """Rows a-5..a-12: cast + contract + encode + MLP on the reference's own gaussians' tdist."""
     g = golden(name)
@@ -266,7 +266,7 @@ def test_mlp_level(name, precision):
 
 
 @pytest.mark.parametrize("name", _names("fwd_"))
-@pytest.mark.parametrize("precision", [_lib.PREC_F32, _lib.PREC_MIXED])
+@pytest.mark.parametrize("precision", [_lib.PREC_F32, _lib.PREC_MIXED, _lib.PREC_FAST])
 def test_model_forward(name, precision):
     """Whole Model.forward (rows a-1..a-16) against the reference run, via the drop-in `Model` class."""
     g = golden(name)
