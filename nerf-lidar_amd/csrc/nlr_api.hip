@@ -17,7 +17,7 @@ void nlr_set_error(const char *fmt, ...) {
 extern "C" const char *nlr_last_error(void) { return g_err; }
 extern "C" int nlr_version(void) { return 100; }
 extern "C" const char *nlr_kernel_names(void) {
-    return "nlr_resample_kernel,nlr_prop_kernel,nlr_encode_kernel,nlr_dirbias_kernel,nlr_mlp_kernel,nlr_composite_kernel";
+    return "nlr_resample_kernel,nlr_prop_kernel,nlr_encode_kernel,nlr_direnc_kernel,nlr_mlp_kernel,nlr_composite_kernel";
 }
 
 // ---- optional per-kernel event timing ---------------------------------------------------------------
@@ -60,9 +60,8 @@ struct LevelModel {
     void *tape = nullptr;
     uint32_t tape_chunks = 0;
     float rgb_premul = 1.0f, rgb_bias = 0.0f, rgb_padding = 0.001f;
-    float *b_d0 = nullptr, *b_d2 = nullptr, *b_h1 = nullptr, *b_h2 = nullptr;
-    float *b_vl = nullptr, *b_rgb = nullptr;
-    float *wd0 = nullptr, *wd1 = nullptr, *b0 = nullptr, *b1 = nullptr;  // dir-encoding columns + biases of layers 0/1
+    float *bias_all = nullptr;
+    uint32_t bias_count = 0;
     float *u_det = nullptr, *u_rand = nullptr;                            // sample positions [S]
     float max_jitter = 0.0f;
 };
@@ -155,8 +154,10 @@ static std::vector<uint16_t> pack_x3(const Mat &w, uint32_t OT, uint32_t KG) {
     return p;
 }
 
-// The weight tape: GEMMs appended in the order nlr_mlp_kernel consumes them, each padded to whole 16 KiB chunks.
+// The weight tape: GEMMs appended in the order nlr_mlp_kernel consumes them, each padded to whole chunks of NLR_TAPE_CHUNK bytes
+// (must equal NLR_CHUNK_FRAGS KiB in nlr_mlp.hip).
 enum { TAPE_F32 = 0, TAPE_BF16 = 1, TAPE_X3 = 2 };
+#define NLR_TAPE_CHUNK 32768
 struct TapeBuilder {
     std::vector<uint8_t> bytes;
     void add(const Mat &w, uint32_t out_pad, uint32_t in_pad, int kind) {
@@ -171,7 +172,7 @@ struct TapeBuilder {
             auto p = pack_x3(w, OT, (in_pad + 15) / 16);
             bytes.insert(bytes.end(), (const uint8_t *)p.data(), (const uint8_t *)(p.data() + p.size()));
         }
-        bytes.resize((bytes.size() + 16383) / 16384 * 16384, 0);
+        bytes.resize((bytes.size() + NLR_TAPE_CHUNK - 1) / NLR_TAPE_CHUNK * NLR_TAPE_CHUNK, 0);
     }
 };
 
@@ -246,11 +247,15 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     const int crit = (prec == NLR_PREC_FAST) ? TAPE_X3 : TAPE_F32;   // density trunk + heads
     const int view = (prec == NLR_PREC_F32) ? TAPE_F32 : TAPE_BF16;  // view MLP
     TapeBuilder tb;
+    std::vector<float> bias;  // b_d0 | b_d2 | b_h1 | b_h2 | view0 | view1 | view2.. | rgb, each padded to whole tiles
+    auto push_bias = [&](const float *b, uint32_t n, uint32_t pad) {
+        for (uint32_t i = 0; i < pad; ++i) bias.push_back(i < n ? b[i] : 0.0f);
+    };
     // density trunk
     tb.add(mat_from(d.density0, 0, lv.F), 64, Fpad, crit);
-    if ((rc = upload_bias(m, d.density0.bias, 64, 64, &lv.b_d0))) return rc;
+    push_bias(d.density0.bias, 64, 64);
     tb.add(mat_from(d.density2, 0, 64), lv.WB, 64, crit);
-    if ((rc = upload_bias(m, d.density2.bias, lv.WB, lv.WB, &lv.b_d2))) return rc;
+    push_bias(d.density2.bias, lv.WB, lv.WB);
     // heads: [sem0 ; int0] stacked, then a block-diagonal [sem2 | 0 ; 0 | int2] into one 32-row tile
     if (lv.HT) {
         const uint32_t HH = lv.HT * 32;
@@ -282,39 +287,37 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
             b2[lv.int_row] = d.int2.bias[0];
         }
         tb.add(h1, HH, lv.WB, crit);
-        if ((rc = upload_bias(m, b1.data(), HH, HH, &lv.b_h1))) return rc;
+        push_bias(b1.data(), HH, HH);
         tb.add(h2, 32, HH, crit);
-        if ((rc = upload_bias(m, b2.data(), 32, 32, &lv.b_h2))) return rc;
+        push_bias(b2.data(), 32, 32);
+    } else {
+        push_bias(nullptr, 0, 32);  // keeps the block layout of the kernel (OB_H2 slot)
     }
     // view MLP.  Input of layer 0 = [bottleneck (WB) | dir_enc (E)]; of layer 1 = [x (W) | bottleneck | dir_enc]
+    // (models.py:1223-1228).  The E dir-encoding columns are zero-padded to one 32-feature tile.
     const uint32_t in0 = lv.WB + lv.E, in1 = lv.W + in0;
     if ((rc = check_linear(d.view[0], lv.W, in0, "lin_second_stage_0"))) return rc;
     if ((rc = check_linear(d.view[1], lv.W, in1, "lin_second_stage_1"))) return rc;
-    tb.add(mat_from(d.view[0], 0, lv.WB), lv.W, lv.WB, view);
+    NLR_CHECK_ARG(lv.E <= 32, "deg_view %u gives %u > 32 direction features -- no fused path", lv.deg, lv.E);
+    tb.add(mat_from(d.view[0], 0, in0), lv.W, lv.WB + 32, view);
+    push_bias(d.view[0].bias, lv.W, lv.W);
     tb.add(mat_from(d.view[1], 0, lv.W), lv.W, lv.W, view);
-    tb.add(mat_from(d.view[1], lv.W, lv.WB), lv.W, lv.WB, view);
-    {
-        Mat e0 = mat_from(d.view[0], lv.WB, lv.E), e1 = mat_from(d.view[1], lv.W + lv.WB, lv.E);
-        if ((rc = dev_upload(m, e0.a.data(), e0.a.size() * 4, (void **)&lv.wd0))) return rc;
-        if ((rc = dev_upload(m, e1.a.data(), e1.a.size() * 4, (void **)&lv.wd1))) return rc;
-        if ((rc = dev_upload(m, d.view[0].bias, lv.W * 4, (void **)&lv.b0))) return rc;
-        if ((rc = dev_upload(m, d.view[1].bias, lv.W * 4, (void **)&lv.b1))) return rc;
-    }
-    {
-        std::vector<float> bl((size_t)(lv.D > 2 ? lv.D - 2 : 1) * lv.W, 0.0f);
-        for (uint32_t l = 2; l < lv.D; ++l) {
-            char nm[64];
-            snprintf(nm, sizeof(nm), "lin_second_stage_%u", l);
-            if ((rc = check_linear(d.view[l], lv.W, lv.W, nm))) return rc;
-            tb.add(mat_from(d.view[l], 0, lv.W), lv.W, lv.W, view);
-            memcpy(&bl[(size_t)(l - 2) * lv.W], d.view[l].bias, lv.W * 4);
-        }
-        if ((rc = dev_upload(m, bl.data(), bl.size() * 4, (void **)&lv.b_vl))) return rc;
+    tb.add(mat_from(d.view[1], lv.W, in0), lv.W, lv.WB + 32, view);
+    push_bias(d.view[1].bias, lv.W, lv.W);
+    for (uint32_t l = 2; l < lv.D; ++l) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "lin_second_stage_%u", l);
+        if ((rc = check_linear(d.view[l], lv.W, lv.W, nm))) return rc;
+        tb.add(mat_from(d.view[l], 0, lv.W), lv.W, lv.W, view);
+        push_bias(d.view[l].bias, lv.W, lv.W);
     }
     if ((rc = check_linear(d.rgb_layer, 3, lv.W, "rgb_layer"))) return rc;
     tb.add(mat_from(d.rgb_layer, 0, lv.W), 32, lv.W, view);
-    if ((rc = upload_bias(m, d.rgb_layer.bias, 3, 32, &lv.b_rgb))) return rc;
-    lv.tape_chunks = (uint32_t)(tb.bytes.size() / 16384);
+    push_bias(d.rgb_layer.bias, 3, 32);
+    lv.bias_count = (uint32_t)bias.size();
+    NLR_CHECK_ARG(lv.bias_count <= 4096, "bias block of %u floats exceeds the 4096-float LDS reservation", lv.bias_count);
+    if ((rc = dev_upload(m, bias.data(), bias.size() * 4, (void **)&lv.bias_all))) return rc;
+    lv.tape_chunks = (uint32_t)(tb.bytes.size() / NLR_TAPE_CHUNK);
     if ((rc = dev_upload(m, tb.bytes.data(), tb.bytes.size(), &lv.tape))) return rc;
     return NLR_OK;
 }
@@ -432,7 +435,7 @@ static size_t level_ws(const LevelModel &lv, uint32_t N, bool last) {
         b += al((size_t)N * S * 3 * 4);                  // rgb
         b += al((size_t)N * S * (lv.K ? lv.K : 1) * 4);  // semantic
         b += al((size_t)N * S * 4);                      // intensity
-        b += al((size_t)N * 2 * lv.W * 4);               // per-ray bias
+        b += al((size_t)N * 32 * 4);                     // per-ray direction encoding
     }
     (void)last;
     return b;
@@ -462,19 +465,14 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     }
     if (rgb) {
         NLR_CHECK_ARG(rays->viewdirs != nullptr, "NerfMLP: viewdirs is NULL");
-        DirBiasParams dp;
+        DirEncParams dp;
         dp.viewdirs = rays->viewdirs;
-        dp.wd0 = lv.wd0;
-        dp.wd1 = lv.wd1;
-        dp.b0 = lv.b0;
-        dp.b1 = lv.b1;
         dp.N = N;
-        dp.W = lv.W;
         dp.deg = lv.deg;
         dp.E = lv.E;
         dp.out = raybias;
         ProfScope ps(&m->prof, NLR_K_DIRBIAS, st);
-        if ((rc = nlr_launch_dirbias(dp, st))) return rc;
+        if ((rc = nlr_launch_direnc(dp, st))) return rc;
     }
     MlpParams P;
     memset(&P, 0, sizeof(P));
@@ -484,13 +482,9 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     P.F = lv.F;
     P.tape = (const uint4 *)lv.tape;
     P.tape_chunks = lv.tape_chunks;
-    P.b_d0 = lv.b_d0;
-    P.b_d2 = lv.b_d2;
-    P.b_h1 = lv.b_h1;
-    P.b_h2 = lv.b_h2;
-    P.b_vl = lv.b_vl;
-    P.b_rgb = lv.b_rgb;
-    P.raybias = raybias;
+    P.bias_all = lv.bias_all;
+    P.bias_count = lv.bias_count;
+    P.enc = raybias;
     P.depth = lv.D;
     P.K = sem ? lv.K : 0;
     P.int_row = lv.int_row;
@@ -519,7 +513,7 @@ extern "C" int nlr_mlp_level(const NlrModel *m, uint32_t level, const NlrRays *r
                              nullptr, features, st);
     Carve c(workspace, workspace_bytes);
     float *feat = features ? features : c.take((size_t)N * lv.S * lv.F);
-    float *rb = c.take((size_t)N * 2 * lv.W);
+    float *rb = c.take((size_t)N * 32);
     float *sem = semantic ? semantic : (lv.K ? c.take((size_t)N * lv.S * lv.K) : nullptr);
     if (c.off > workspace_bytes || (!workspace && c.off))
         NLR_FAIL(NLR_ERR_WORKSPACE, "mlp_level: workspace %zu B < needed %zu B", workspace_bytes, c.off);
@@ -568,7 +562,7 @@ extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t 
         float *feat = nullptr, *rb = nullptr, *rgb = nullptr, *sem = nullptr, *inten = nullptr;
         if (!lv.is_prop) {
             feat = c.take((size_t)N * S * lv.F);
-            rb = c.take((size_t)N * 2 * lv.W);
+            rb = c.take((size_t)N * 32);
             rgb = ho.rgb ? ho.rgb : c.take((size_t)N * S * 3);
             sem = lv.K ? (ho.semantic ? ho.semantic : c.take((size_t)N * S * lv.K)) : nullptr;
             inten = lv.use_int ? (ho.intensity ? ho.intensity : c.take((size_t)N * S)) : nullptr;

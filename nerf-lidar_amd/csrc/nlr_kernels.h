@@ -39,22 +39,21 @@ struct MlpParams {
     // D0, D2, [H1, H2], V0, V1a, V1b, V2..V(D-1), RGB; each GEMM padded to whole 16 KiB chunks.
     const uint4 *tape;
     uint32_t tape_chunks;
-    const float *b_d0, *b_d2, *b_h1, *b_h2;  // padded to 32*OT
-    const float *b_vl;      // [(D-2), W]
-    const float *b_rgb;     // [32]
-    const float *raybias;   // [N, 2, W] per-ray bias of layers 0 and 1 (bias + dir_enc columns)
+    // all biases, concatenated and zero-padded to whole 32-row tiles, copied to LDS once per workgroup:
+    // b_d0 (64) | b_d2 (WB) | b_h1 (32*HT) | b_h2 (32) | view0 (W) | view1 (W) | view2.. (W each) | rgb (32)
+    const float *bias_all;
+    uint32_t bias_count;
+    const float *enc;       // [N, 32] per-ray direction encoding (27 values + zero padding), one extra input tile
     uint32_t depth;         // net_depth_viewdirs
     uint32_t K, int_row;    // class_num (0 = no semantic head), row of the intensity output (or 0xffffffff)
     float density_bias, rgb_premul, rgb_bias, rgb_padding;
     float *density, *rgb, *sem, *inten;  // outputs: [M], [M,3], [M,K], [M]
 };
 
-struct DirBiasParams {
-    const float *viewdirs;   // [N,3]
-    const float *wd0, *wd1;  // [W, E] dir-encoding columns of lin_second_stage_0 / _1
-    const float *b0, *b1;    // [W]
-    uint32_t N, W, deg, E;
-    float *out;              // [N, 2, W]
+struct DirEncParams {
+    const float *viewdirs;  // [N,3]
+    uint32_t N, deg, E;
+    float *out;             // [N, 32]
 };
 
 int nlr_launch_resample(const float *prev_sdist, const float *prev_weights, uint32_t n_prev, float dilation, float anneal,
@@ -65,6 +64,6 @@ int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist
 int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, hipStream_t st);
 int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1, const float *b1, const float *w2, float b2,
                     float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st);
-int nlr_launch_dirbias(const DirBiasParams &P, hipStream_t st);
+int nlr_launch_direnc(const DirEncParams &P, hipStream_t st);
 int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, hipStream_t st);
 int nlr_launch_composite(const CompositeParams &P, hipStream_t st);
