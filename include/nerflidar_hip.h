@@ -167,8 +167,8 @@ typedef struct NlrRenderCfg {
 typedef struct NlrLevelOut {         /* one ray_history entry (models.py:553-557); any may be NULL */
     float *sdist, *tdist;            /* [N, S+1] */
     float *weights, *density;        /* [N, S] */
-    float *rgb;                      /* [N, S, 3]  (final level) */
-    float *semantic;                 /* [N, S, class_num] probabilities (final level) */
+    float *rgb;                      /* channel-major [3, N, S]  (final level) */
+    float *semantic;                 /* class-major [class_num, N, S] probabilities (final level) */
     float *intensity;                /* [N, S] (final level) */
     float *depth;                    /* [N] per-level rendering['depth'] */
 } NlrLevelOut;
@@ -212,14 +212,16 @@ int nlr_resample_level(const float *prev_sdist, const float *prev_weights, uint3
                        const float *rand_jitter, const float *near, const float *far,
                        float power_lambda, uint32_t N, float *sdist, float *tdist, void *stream);
 
-/* a-5..a-12: cast + contract + encode + MLP for level `level` of the model.  tdist [N,S+1]. */
+/* a-5..a-12: cast + contract + encode + MLP for level `level` of the model.  tdist [N,S+1].
+ * density [N,S]; rgb channel-major [3,N,S]; semantic class-major [K,N,S]; intensity [N,S]. */
 int nlr_mlp_level(const NlrModel *m, uint32_t level, const NlrRays *rays, const float *tdist,
                   uint32_t N, uint32_t sample_n, uint32_t sample_m, const float *rand_deg,
                   float *features /* [N*S, L*C] or NULL */, float *density, float *rgb,
                   float *semantic, float *intensity, void *workspace, size_t workspace_bytes,
                   void *stream);
 
-/* a-13 + a-14 (+ a-16 post-step when labels/points are given). */
+/* a-13 + a-14 (+ a-16 post-step when labels/points are given).  rgb [3,N,S] and semantic [K,N,S] are
+ * channel-/class-major (what nlr_mlp_level writes: coalesced for both kernels). */
 int nlr_composite_level(const float *density, const float *tdist, const float *directions,
                         const float *rgb, const float *semantic, const float *intensity,
                         const float *far, const float *origins, uint32_t N, uint32_t S,

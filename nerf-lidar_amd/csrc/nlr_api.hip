@@ -109,28 +109,29 @@ static Mat mat_from(const NlrLinear &l, uint32_t col0, uint32_t ncols) {
     return m;
 }
 
-// f32 fragments: [kgroup][otile][lane] float4; lane (i = lane&31, h = lane>>5), element e:
+// Fragment order is output-tile-major, [otile][kgroup] (the order nlr_gemm consumes them).
+// f32 fragments: [otile][kgroup][lane] float4; lane (i = lane&31, h = lane>>5), element e:
 //   row = 32*o + i, input feature = 8*g + 4*h + e    (k-step s = 4*(g&3)+e of input tile g>>2 reads accumulator
 //   register s, whose feature row for lane half h is (s&3) + 8*(s>>2) + 4*h = e + 8*(g&3) + 4*h)
 static std::vector<float> pack_f32(const Mat &w, uint32_t OT, uint32_t KG) {
     std::vector<float> p((size_t)KG * OT * 64 * 4);
-    for (uint32_t g = 0; g < KG; ++g)
-        for (uint32_t o = 0; o < OT; ++o)
+    for (uint32_t o = 0; o < OT; ++o)
+        for (uint32_t g = 0; g < KG; ++g)
             for (uint32_t lane = 0; lane < 64; ++lane)
                 for (uint32_t e = 0; e < 4; ++e)
-                    p[(((size_t)g * OT + o) * 64 + lane) * 4 + e] = w.get(32 * o + (lane & 31), 8 * g + 4 * (lane >> 5) + e);
+                    p[(((size_t)o * KG + g) * 64 + lane) * 4 + e] = w.get(32 * o + (lane & 31), 8 * g + 4 * (lane >> 5) + e);
     return p;
 }
 
-// bf16 fragments: [kstep][otile][lane] 8 x bf16; element j of lane half h is input feature
+// bf16 fragments: [otile][kstep][lane] 8 x bf16; element j of lane half h is input feature
 //   16*g + 8*(j>>2) + 4*h + (j&3)   (the k order of an accumulator tile reused as B operand)
 static std::vector<uint16_t> pack_bf16(const Mat &w, uint32_t OT, uint32_t KG) {
     std::vector<uint16_t> p((size_t)KG * OT * 64 * 8);
-    for (uint32_t g = 0; g < KG; ++g)
-        for (uint32_t o = 0; o < OT; ++o)
+    for (uint32_t o = 0; o < OT; ++o)
+        for (uint32_t g = 0; g < KG; ++g)
             for (uint32_t lane = 0; lane < 64; ++lane)
                 for (uint32_t j = 0; j < 8; ++j)
-                    p[(((size_t)g * OT + o) * 64 + lane) * 8 + j] =
+                    p[(((size_t)o * KG + g) * 64 + lane) * 8 + j] =
                         f32_to_bf16(w.get(32 * o + (lane & 31), 16 * g + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)));
     return p;
 }
@@ -138,8 +139,8 @@ static std::vector<uint16_t> pack_bf16(const Mat &w, uint32_t OT, uint32_t KG) {
 // split-bf16 fragments: for every (kstep, otile) the hi fragment then the lo fragment (W = hi + lo)
 static std::vector<uint16_t> pack_x3(const Mat &w, uint32_t OT, uint32_t KG) {
     std::vector<uint16_t> p((size_t)KG * OT * 2 * 64 * 8);
-    for (uint32_t g = 0; g < KG; ++g)
-        for (uint32_t o = 0; o < OT; ++o)
+    for (uint32_t o = 0; o < OT; ++o)
+        for (uint32_t g = 0; g < KG; ++g)
             for (uint32_t lane = 0; lane < 64; ++lane)
                 for (uint32_t j = 0; j < 8; ++j) {
                     const float v = w.get(32 * o + (lane & 31), 16 * g + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3));
@@ -147,7 +148,7 @@ static std::vector<uint16_t> pack_x3(const Mat &w, uint32_t OT, uint32_t KG) {
                     uint32_t hb = (uint32_t)hi << 16;
                     float hf;
                     memcpy(&hf, &hb, 4);
-                    const size_t base = (((size_t)g * OT + o) * 2) * 64 * 8;
+                    const size_t base = (((size_t)o * KG + g) * 2) * 64 * 8;
                     p[base + (size_t)lane * 8 + j] = hi;
                     p[base + 64 * 8 + (size_t)lane * 8 + j] = f32_to_bf16(v - hf);
                 }
@@ -160,7 +161,10 @@ enum { TAPE_F32 = 0, TAPE_BF16 = 1, TAPE_X3 = 2 };
 #define NLR_TAPE_CHUNK 32768
 struct TapeBuilder {
     std::vector<uint8_t> bytes;
-    void add(const Mat &w, uint32_t out_pad, uint32_t in_pad, int kind) {
+    // even_chunks: pad to an even number of chunks (the view layers >= 2 sit in a runtime loop whose chunk parity
+    // must not change from one iteration to the next; see Tape::step in nlr_mlp.hip)
+    void add(const Mat &w, uint32_t out_pad, uint32_t in_pad, int kind, bool even_chunks = false) {
+        const size_t start = bytes.size();
         const uint32_t OT = out_pad / 32;
         if (kind == TAPE_F32) {
             auto p = pack_f32(w, OT, in_pad / 8);
@@ -173,6 +177,7 @@ struct TapeBuilder {
             bytes.insert(bytes.end(), (const uint8_t *)p.data(), (const uint8_t *)(p.data() + p.size()));
         }
         bytes.resize((bytes.size() + NLR_TAPE_CHUNK - 1) / NLR_TAPE_CHUNK * NLR_TAPE_CHUNK, 0);
+        if (even_chunks && (((bytes.size() - start) / NLR_TAPE_CHUNK) & 1)) bytes.resize(bytes.size() + NLR_TAPE_CHUNK, 0);
     }
 };
 
@@ -301,14 +306,13 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     NLR_CHECK_ARG(lv.E <= 32, "deg_view %u gives %u > 32 direction features -- no fused path", lv.deg, lv.E);
     tb.add(mat_from(d.view[0], 0, in0), lv.W, lv.WB + 32, view);
     push_bias(d.view[0].bias, lv.W, lv.W);
-    tb.add(mat_from(d.view[1], 0, lv.W), lv.W, lv.W, view);
-    tb.add(mat_from(d.view[1], lv.W, in0), lv.W, lv.WB + 32, view);
+    tb.add(mat_from(d.view[1], 0, in1), lv.W, lv.W + lv.WB + 32, view);
     push_bias(d.view[1].bias, lv.W, lv.W);
     for (uint32_t l = 2; l < lv.D; ++l) {
         char nm[64];
         snprintf(nm, sizeof(nm), "lin_second_stage_%u", l);
         if ((rc = check_linear(d.view[l], lv.W, lv.W, nm))) return rc;
-        tb.add(mat_from(d.view[l], 0, lv.W), lv.W, lv.W, view);
+        tb.add(mat_from(d.view[l], 0, lv.W), lv.W, lv.W, view, true);
         push_bias(d.view[l].bias, lv.W, lv.W);
     }
     if ((rc = check_linear(d.rgb_layer, 3, lv.W, "rgb_layer"))) return rc;
@@ -318,6 +322,7 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     NLR_CHECK_ARG(lv.bias_count <= 4096, "bias block of %u floats exceeds the 4096-float LDS reservation", lv.bias_count);
     if ((rc = dev_upload(m, bias.data(), bias.size() * 4, (void **)&lv.bias_all))) return rc;
     lv.tape_chunks = (uint32_t)(tb.bytes.size() / NLR_TAPE_CHUNK);
+    tb.bytes.resize(tb.bytes.size() + 3 * NLR_TAPE_CHUNK, 0);  // slack: the kernel prefetches up to 3 chunks past the end
     if ((rc = dev_upload(m, tb.bytes.data(), tb.bytes.size(), &lv.tape))) return rc;
     return NLR_OK;
 }

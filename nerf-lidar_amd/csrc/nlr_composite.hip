@@ -78,17 +78,18 @@ __global__ void __launch_bounds__(256) nlr_composite_kernel(CompositeParams P) {
             if (P.extras) slog += wk * logf(tm[i]);
             if (P.weights) P.weights[(size_t)ray * S + k] = wk;
             if (P.rgb) {
-                const float *c3 = P.rgb + ((size_t)ray * S + k) * 3;
-                srgb[0] += wk * c3[0];
-                srgb[1] += wk * c3[1];
-                srgb[2] += wk * c3[2];
+                const size_t mi = (size_t)ray * S + k, Mt = (size_t)P.N * S;  // channel-major [3, N*S]
+                srgb[0] += wk * P.rgb[mi];
+                srgb[1] += wk * P.rgb[Mt + mi];
+                srgb[2] += wk * P.rgb[2 * Mt + mi];
             }
             if (P.inten) sint += wk * P.inten[(size_t)ray * S + k];
             if (P.sem) {
-                const float *ps = P.sem + ((size_t)ray * S + k) * P.K;
+                const float *ps = P.sem + (size_t)ray * S + k;  // class-major [K, N*S]
+                const size_t Mt = (size_t)P.N * S;
 #pragma unroll
                 for (int c = 0; c < NLR_COMP_MAXK; ++c)
-                    if (c < (int)P.K) ssem[c] += wk * ps[c];
+                    if (c < (int)P.K) ssem[c] += wk * ps[(size_t)c * Mt];
             }
         }
     }

@@ -36,7 +36,7 @@ struct MlpParams {
     const float *feat;      // [M, F] f32
     uint32_t M, S, F;       // samples, samples per ray, feature count
     // Weight tape: every GEMM's A fragments (1 KiB each: 64 lanes x 16 B) in consumption order
-    // D0, D2, [H1, H2], V0, V1a, V1b, V2..V(D-1), RGB; each GEMM padded to whole 16 KiB chunks.
+    // D0, D2, [H1, H2], V0, V1, V2..V(D-1), RGB (fragments output-tile-major); each GEMM padded to whole 32 KiB chunks.
     const uint4 *tape;
     uint32_t tape_chunks;
     // all biases, concatenated and zero-padded to whole 32-row tiles, copied to LDS once per workgroup:
@@ -47,7 +47,7 @@ struct MlpParams {
     uint32_t depth;         // net_depth_viewdirs
     uint32_t K, int_row;    // class_num (0 = no semantic head), row of the intensity output (or 0xffffffff)
     float density_bias, rgb_premul, rgb_bias, rgb_padding;
-    float *density, *rgb, *sem, *inten;  // outputs: [M], [M,3], [M,K], [M]
+    float *density, *rgb, *sem, *inten;  // outputs: [M], channel-major [3,M], class-major [K,M], [M]
 };
 
 struct DirEncParams {

@@ -1,0 +1,510 @@
+// NerfMLP evaluation on the matrix cores: density trunk -> semantic/intensity heads -> view MLP -> rgb.
+//
+// Replaces (rows a-9..a-12 of the scope table):
+//   ZI/models.py:887-889, 996-997, 1116     density_layer (F->64->256), softplus(raw - 1)
+//   ZI/models.py:954-961, 1124-1143         sem_layer (256->64->19, softmax), intensity_layer (256->64->1)
+//   ZI/coord.py:199-210, models.py:1190-1196  pos_enc(viewdirs) broadcast over samples
+//   ZI/models.py:939-951, 1223-1234, 1251   lin_second_stage_i (+skip concat after layer 0), rgb_layer, sigmoid, padding
+//
+// Design (CDNA4, not a translation of the nn.Linear chain):
+//   * the whole chain runs TRANSPOSED, activations^T = W . x^T, so that an MFMA result tile (32 output
+//     features x 32 samples: sample on the lane, features in the 16 accumulator registers) is already
+//     the B operand of the next layer's MFMA (cdna_hip_programming.md section 3, "An accumulator tile as
+//     the next MFMA's operand").  Activations never leave the register file: no LDS round trip, no
+//     barrier between the 8+ layers.  One wavefront owns 32 samples end to end.
+//   * weights are the A operand, pre-packed at model-create time into exactly the per-lane fragment
+//     order (including the permuted k order the accumulator layout implies), so every fragment fetch is
+//     one fully coalesced 16-byte-per-lane load of 1 KiB per wavefront.
+//   * the 27 direction-encoding features are computed once per ray by a small pre-kernel and ride through view
+//     layers 0 and 1 as one extra zero-padded 32-feature input tile, so every GEMM has K % 32 == 0;
+//   * nothing but the weight tape is read from global memory after the prologue: all biases sit in LDS.
+//   * precision: layers whose error reaches depth / semantic argmax / intensity (density trunk, heads)
+//     use the exact-f32 MFMA (v_mfma_f32_32x32x2_f32); the view MLP (rgb only, 92 % of the MACs) uses
+//     bf16 MFMA (v_mfma_f32_32x32x16_bf16) with f32 accumulation.  NLR_PREC_F32 runs everything in f32.
+#pragma once
+#include "nlr_kernels.h"
+
+#include <type_traits>
+
+
+// row of accumulator register r for lane half h inside a 32-row tile
+__device__ __forceinline__ int nlr_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- weight tape: global -> registers -> LDS (triple buffered), shared by the 4 waves of a workgroup -----------
+// A chunk is 32 KiB = 32 fragments of 1 KiB (one fragment = the A operand of one MFMA for all 64 lanes).  Every
+// wave needs every fragment (each wave owns 32 samples and all output features), so staging through LDS cuts the
+// L2 -> CU weight traffic 4x against per-wave global loads and puts the fragment reads on ds_read_b128.
+// Schedule inside chunk c (f = fragment position, all positions are compile-time after unrolling):
+//   f = 20  the 256 threads write chunk c+1 (in registers since chunk c-2, f = 22) into LDS buffer (c+1)%3
+//   f = 21  __syncthreads(): chunk c+1 is visible to every wave
+//   f = 22  global loads of chunk c+3 are issued: two chunks (64 KiB per CU) are always in flight from L2, because
+//           one CU pulls only ~30 B/clk from L2 and a 32 KiB chunk is consumed every ~1000 cycles
+//   every f: the fragment f+8 is requested into an 8-deep register ring right after fragment f is consumed; from
+//            f = 24 on these requests run into chunk c+1, so no LDS latency is exposed at a chunk boundary.
+// Three buffers: the write at (20, c) lands in the buffer of chunk c-2, whose last read (31, c-2) lies before the
+// barrier (21, c-1) that every wave has passed; with two buffers it would race with slow waves still in chunk c-1.
+#define NLR_CHUNK_FRAGS 32                       // fragments (1 KiB each) per chunk
+#define NLR_CHUNK_SLOTS (NLR_CHUNK_FRAGS * 64)   // uint4 slots per chunk
+#define NLR_CHUNK_LOADS (NLR_CHUNK_SLOTS / 256)  // 16-byte loads per thread per chunk
+#define NLR_NBUF 3
+#define NLR_PF 8                                 // fragment read-ahead (register ring)
+struct Tape {
+    const uint4 *__restrict__ base;
+    uint4 *lds;  // [NLR_NBUF][NLR_CHUNK_SLOTS]
+    uint4 na[NLR_CHUNK_LOADS], nb[NLR_CHUNK_LOADS];  // two register sets: odd chunks travel in na, even in nb
+    uint4 ring[NLR_PF];
+    int cur, total, tid, lane;
+    __device__ __forceinline__ uint4 *buf(int c) const { return lds + (c % NLR_NBUF) * NLR_CHUNK_SLOTS; }
+    __device__ __forceinline__ void load(uint4 (&r)[NLR_CHUNK_LOADS], int c) {
+        // uniform base + 32-bit per-lane byte offset: one v_add per load instead of a 64-bit add chain
+        const char *b = reinterpret_cast<const char *>(base);
+        const uint32_t off = ((uint32_t)c * NLR_CHUNK_SLOTS + (uint32_t)tid) * 16u;
+#pragma unroll
+        for (int i = 0; i < NLR_CHUNK_LOADS; ++i) r[i] = *reinterpret_cast<const uint4 *>(b + (off + (uint32_t)i * 4096u));
+    }
+    __device__ __forceinline__ void store(const uint4 (&r)[NLR_CHUNK_LOADS], int c) {
+        uint4 *q = buf(c) + tid;
+#pragma unroll
+        for (int i = 0; i < NLR_CHUNK_LOADS; ++i) q[i * 256] = r[i];
+    }
+    __device__ __forceinline__ void prologue() {
+        cur = 0;
+        load(nb, 0);
+        store(nb, 0);
+        load(na, 1);  // the tape ends with 3 zero chunks of slack: no bounds checks anywhere in the stream
+        load(nb, 2);
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < NLR_PF; ++f) ring[f] = buf(0)[f * 64 + lane];
+    }
+    // bookkeeping at fragment position F of the current chunk; returns the fragment (raw 16 bytes per lane).
+    // Two chunks are always in flight from L2: chunk c+1 (stored at F = 20 of chunk c) and chunk c+2; chunk c+3
+    // is requested at F = 22 into the register set chunk c+1 just left.
+    // PAR = parity of the current chunk index (a compile-time fact of the fixed GEMM sequence), so the register
+    // set is selected statically: chunks c+1 and c+3 have parity 1-PAR.
+    template <int F, int PAR>
+    __device__ __forceinline__ uint4 step() {
+        if constexpr (F == 20) {
+            if constexpr (PAR == 0) store(na, cur + 1); else store(nb, cur + 1);
+        }
+        if constexpr (F == 21) __syncthreads();
+        if constexpr (F == 22) {
+            if constexpr (PAR == 0) load(na, cur + 3); else load(nb, cur + 3);
+        }
+        const uint4 a = ring[F % NLR_PF];
+        if constexpr (F + NLR_PF < NLR_CHUNK_FRAGS) ring[F % NLR_PF] = buf(cur)[(F + NLR_PF) * 64 + lane];
+        else ring[F % NLR_PF] = buf(cur + 1)[(F + NLR_PF - NLR_CHUNK_FRAGS) * 64 + lane];
+        if constexpr (F == NLR_CHUNK_FRAGS - 1) ++cur;
+        return a;
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ T nlr_as(const uint4 &v) {
+    return __builtin_bit_cast(T, v);
+}
+
+template <int I>
+using ic = std::integral_constant<int, I>;
+
+// number of 32-fragment chunks a GEMM occupies on the tape
+constexpr int nlr_nch(int ot, int kg, int fps) { return (ot * kg * fps + NLR_CHUNK_FRAGS - 1) / NLR_CHUNK_FRAGS; }
+
+// steps over the unused tail of a GEMM's last chunk (its bookkeeping positions must still run)
+template <int F, int PAR>
+__device__ __forceinline__ void nlr_pad(Tape &tp) {
+    if constexpr (F != 0) {
+        (void)tp.template step<F, PAR>();
+        nlr_pad<(F + 1) % NLR_CHUNK_FRAGS, PAR>(tp);
+    }
+}
+template <int F, int PAR>
+__device__ __forceinline__ void nlr_pad_chunk(Tape &tp) {  // one whole padding chunk
+    (void)tp.template step<F, PAR>();
+    if constexpr (F + 1 < NLR_CHUNK_FRAGS) nlr_pad_chunk<F + 1, PAR>(tp);
+}
+
+// Output-tile-major GEMM driver: for each 32-row output tile o, run all KG k-steps into ONE accumulator, then
+// hand the finished tile to `epi`.  Only two accumulator tiles are live (current + the one being post-processed),
+// and the epilogue of tile o-1 (ReLU / bf16 conversion / hi-lo split: ~80 VALU instructions) sits in the
+// instruction stream right behind the first MFMA of tile o, so it executes in the shadow of tile o's MFMA chain
+// instead of serialising between layers (the kernel runs one wave per SIMD: nothing else would hide it).
+//   FPS = fragments per k-step (1; 2 for the hi/lo pairs of the split-bf16 path); PAR0 = parity of the first chunk
+//   init(ic<o>) -> f32x16 bias tile;  step(acc&, ic<g>, frag0, frag1);  epi(ic<o>, acc)
+template <int OT, int KG, int FPS, int PAR0, int IDX, class Init, class Step, class Epi>
+__device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, const Init &init, const Step &step, const Epi &epi) {
+    if constexpr (IDX < OT * KG) {
+        constexpr int o = IDX / KG, g = IDX % KG;
+        if constexpr (g == 0) {
+            if constexpr (o > 0) prev = cur;
+            cur = init(ic<o>{});
+        }
+        constexpr int P0 = (IDX * FPS) % NLR_CHUNK_FRAGS;
+        constexpr int PAR = (PAR0 + (IDX * FPS) / NLR_CHUNK_FRAGS) & 1;
+        const uint4 f0 = tp.template step<P0, PAR>();
+        uint4 f1 = f0;
+        if constexpr (FPS == 2) f1 = tp.template step<P0 + 1, PAR>();
+        step(cur, ic<g>{}, f0, f1);
+        if constexpr (g == 0 && o > 0) epi(ic<o - 1>{}, prev);
+        nlr_run<OT, KG, FPS, PAR0, IDX + 1>(tp, prev, cur, init, step, epi);
+    } else {
+        epi(ic<OT - 1>{}, cur);
+        nlr_pad<(OT * KG * FPS) % NLR_CHUNK_FRAGS, (PAR0 + nlr_nch(OT, KG, FPS) - 1) & 1>(tp);
+    }
+}
+// EVEN: the GEMM is followed by one padding chunk when its chunk count is odd (keeps the parity of a runtime layer loop)
+template <int OT, int KG, int FPS, int PAR0, bool EVEN = false, class Init, class Step, class Epi>
+__device__ __forceinline__ void nlr_gemm(Tape &tp, const Init &init, const Step &step, const Epi &epi) {
+    f32x16 prev, cur;
+    nlr_run<OT, KG, FPS, PAR0, 0>(tp, prev, cur, init, step, epi);
+    if constexpr (EVEN && (nlr_nch(OT, KG, FPS) & 1)) nlr_pad_chunk<0, (PAR0 + nlr_nch(OT, KG, FPS)) & 1>(tp);
+}
+
+__device__ __forceinline__ f32x16 nlr_bias_tile(const float *bias, int o, int h) {
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(bias + o * 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[q * 4 + e] = v[e];
+    }
+    return a;
+}
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// ReLU is applied AFTER the conversion, on the packed pairs: a negative bf16 is a negative int16, so one
+// v_pk_max_i16 against zero clears two values (half the VALU work of v_max_f32 per value; -0.0 -> +0.0).
+template <bool RELU>
+__device__ __forceinline__ void nlr_pack1(TileH &dst, const f32x16 &src) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)src[8 * s + j];
+        if (RELU) {
+            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            v = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+        }
+        dst.f[s] = v;
+    }
+}
+// hi = bf16(x), lo = bf16(x - hi)   (x - hi is exact in f32)
+template <bool RELU>
+__device__ __forceinline__ void nlr_split1(TileH &hi, TileH &lo, const f32x16 &src) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = src[8 * s + j];
+            if (RELU) v = fmaxf(v, 0.0f);
+            const __bf16 hh = (__bf16)v;
+            hi.f[s][j] = hh;
+            lo.f[s][j] = (__bf16)(v - (float)hh);
+        }
+}
+template <bool RELU>
+__device__ __forceinline__ f32x16 nlr_act(const f32x16 &src) {
+    f32x16 r = src;
+    if (RELU) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[i] = fmaxf(r[i], 0.0f);
+    }
+    return r;
+}
+
+// MFMA steps ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void nlr_mma_bf16(f32x16 &acc, const uint4 &a, const bf16x8 &b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nlr_as<bf16x8>(a), b, acc, 0, 0, 0);
+}
+// Split-bf16 ("bf16x3"): W = Wh + Wl, x = xh + xl (each part bf16), W.x ~= Wh.xh + Wh.xl + Wl.xh with f32
+// accumulation: 16 mantissa bits per operand (relative error ~2^-16) at 3/16 of the exact-f32 MFMA cost.
+__device__ __forceinline__ void nlr_mma_x3(f32x16 &acc, const uint4 &ah, const uint4 &al, const bf16x8 &bh, const bf16x8 &bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nlr_as<bf16x8>(ah), bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nlr_as<bf16x8>(ah), bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nlr_as<bf16x8>(al), bh, acc, 0, 0, 0);
+}
+// exact-f32 MFMA: one fragment (float4 per lane) carries 4 k-steps of 2 features
+template <int G, int KT>
+__device__ __forceinline__ void nlr_mma_f32(f32x16 &acc, const uint4 &a, const f32x16 (&in)[KT]) {
+    const f32x4 af = nlr_as<f32x4>(a);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], in[G >> 2][(G & 3) * 4 + e], acc, 0, 0, 0);
+}
+
+// WT = view width / 32, BT = bottleneck / 32, FG = ceil(F/8), HT = head hidden tiles (0, 2 or 4)
+// PREC: NLR_PREC_F32 (all f32), NLR_PREC_MIXED (trunk+heads f32, view bf16), NLR_PREC_FAST (trunk+heads bf16x3, view bf16)
+#define NLR_BIAS_MAX 4096  // floats of LDS reserved for the bias block (16 KiB)
+template <int WT, int BT, int FG, int HT, int PREC>
+__global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
+    __shared__ __align__(16) uint4 lds_tape[NLR_NBUF * NLR_CHUNK_SLOTS];
+    __shared__ __align__(16) float lds_bias[NLR_BIAS_MAX];
+    constexpr bool VIEW_F32 = (PREC == NLR_PREC_F32);
+    constexpr bool X3 = (PREC == NLR_PREC_FAST);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const uint32_t sample = (blockIdx.x * 4 + wave) * 32 + col;
+    const bool valid = sample < P.M;
+    const uint32_t sc = valid ? sample : P.M - 1;
+    const uint32_t ray = sc / P.S;
+    constexpr int FT = (FG + 3) / 4;
+    constexpr int HTA = HT > 0 ? HT : 1;
+    // bias block offsets (floats)
+    constexpr int OB_D0 = 0, OB_D2 = 64, OB_H1 = OB_D2 + BT * 32, OB_H2 = OB_H1 + HT * 32, OB_V0 = OB_H2 + 32;
+    constexpr int OB_V1 = OB_V0 + WT * 32, OB_VL = OB_V1 + WT * 32;
+    // chunk parity at the start of every GEMM of the fixed sequence (see Tape::step)
+    constexpr int CF = X3 ? 2 : 1;                     // fragments per k-step in the trunk/heads
+    constexpr int KU = X3 ? 2 : 4;                     // k-steps per 32-feature input tile in the trunk/heads
+    constexpr int KV = VIEW_F32 ? 4 : 2;               // ... in the view MLP
+    constexpr int KD0 = X3 ? (FG + 1) / 2 : FG;
+    constexpr int P_D0 = 0;
+    constexpr int P_D2 = P_D0 + nlr_nch(2, KD0, CF);
+    constexpr int P_H1 = P_D2 + nlr_nch(BT, 2 * KU, CF);
+    constexpr int P_H2 = P_H1 + (HT > 0 ? nlr_nch(HT, BT * KU, CF) : 0);
+    constexpr int P_V0 = P_H2 + (HT > 0 ? nlr_nch(1, HT * KU, CF) : 0);
+    constexpr int P_V1 = P_V0 + nlr_nch(WT, (BT + 1) * KV, 1);
+    constexpr int P_VL = P_V1 + nlr_nch(WT, (WT + BT + 1) * KV, 1);  // layers >= 2 occupy an even number of chunks each
+
+    // ---- everything that comes from global memory besides the weight tape is requested up front: the kernel runs
+    // one wave per SIMD, so a load in the middle of the chain would be pure exposed latency.
+    f32x4 fv[FG];
+    {
+        const float *fp = P.feat + (size_t)sc * P.F;
+#pragma unroll
+        for (int g = 0; g < FG; ++g) {
+            const uint32_t f0 = 8 * g + 4 * h;
+            fv[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (f0 + 4 <= P.F) fv[g] = *reinterpret_cast<const f32x4 *>(fp + f0);
+        }
+    }
+    f32x4 ev[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ev[q] = *reinterpret_cast<const f32x4 *>(P.enc + (size_t)ray * 32 + 8 * q + 4 * h);
+    for (uint32_t i = threadIdx.x * 4; i < P.bias_count; i += 1024)
+        *reinterpret_cast<f32x4 *>(lds_bias + i) = *reinterpret_cast<const f32x4 *>(P.bias_all + i);
+
+    Tape tp;
+    tp.base = P.tape;
+    tp.lds = lds_tape;
+    tp.total = (int)P.tape_chunks;
+    tp.tid = threadIdx.x;
+    tp.lane = lane;
+    tp.prologue();  // ends with __syncthreads(): the bias block is visible too
+
+    // ---- features / direction encoding -> accumulator-layout tiles (lane half h holds rows 8q+4h..+3 of each group)
+    f32x16 fin[FT];
+#pragma unroll
+    for (int t = 0; t < FT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fin[t][r] = 0.0f;
+#pragma unroll
+    for (int g = 0; g < FG; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fin[g >> 2][(g & 3) * 4 + e] = fv[g][e];
+    f32x16 encf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) encf[q * 4 + e] = ev[q][e];
+
+    float raw_density = 0.0f;
+    f32x16 lo;  // [K logits | intensity] output tile of the heads
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lo[r] = 0.0f;
+    TileH hbe[VIEW_F32 ? 1 : BT + 1];      // bf16 [bottleneck | dir-enc] tiles for the view MLP
+    f32x16 hbf[VIEW_F32 ? BT + 1 : 1];     // the same in f32 (NLR_PREC_F32)
+
+    if constexpr (X3) {
+        // ---- density trunk + heads on split-bf16
+        constexpr int FK = (FG + 1) / 2;  // 16-feature k-steps covering the grid features
+        TileH fh[FT], fl[FT];
+#pragma unroll
+        for (int t = 0; t < FT; ++t) nlr_split1<false>(fh[t], fl[t], fin[t]);
+        TileH dh[2], dl[2];
+        nlr_gemm<2, FK, 2, P_D0 & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D0, o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
+                constexpr int G = decltype(g)::value;
+                nlr_mma_x3(a, f0, f1, fh[G >> 1].f[G & 1], fl[G >> 1].f[G & 1]);
+            },
+            [&](auto o, const f32x16 &a) { nlr_split1<true>(dh[decltype(o)::value], dl[decltype(o)::value], a); });
+        TileH hbl[BT];
+        nlr_gemm<BT, 4, 2, P_D2 & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D2, o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
+                constexpr int G = decltype(g)::value;
+                nlr_mma_x3(a, f0, f1, dh[G >> 1].f[G & 1], dl[G >> 1].f[G & 1]);
+            },
+            [&](auto o, const f32x16 &a) {
+                constexpr int O = decltype(o)::value;
+                if constexpr (O == 0) raw_density = a[0];
+                nlr_split1<false>(hbe[O], hbl[O], a);
+            });
+        if constexpr (HT > 0) {
+            TileH qh[HTA], ql[HTA];
+            nlr_gemm<HT, BT * 2, 2, P_H1 & 1>(
+                tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H1, o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
+                    constexpr int G = decltype(g)::value;
+                    nlr_mma_x3(a, f0, f1, hbe[G >> 1].f[G & 1], hbl[G >> 1].f[G & 1]);
+                },
+                [&](auto o, const f32x16 &a) { nlr_split1<true>(qh[decltype(o)::value], ql[decltype(o)::value], a); });
+            nlr_gemm<1, HT * 2, 2, P_H2 & 1>(
+                tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H2, o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
+                    constexpr int G = decltype(g)::value;
+                    nlr_mma_x3(a, f0, f1, qh[G >> 1].f[G & 1], ql[G >> 1].f[G & 1]);
+                },
+                [&](auto, const f32x16 &a) { lo = a; });
+        }
+    } else {
+        // ---- density trunk + heads on the exact-f32 MFMA
+        f32x16 hid[2];
+        nlr_gemm<2, FG, 1, P_D0 & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D0, o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, FT>(a, f0, fin); },
+            [&](auto o, const f32x16 &a) { hid[decltype(o)::value] = nlr_act<true>(a); });
+        f32x16 hb[BT];
+        nlr_gemm<BT, 8, 1, P_D2 & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D2, o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, 2>(a, f0, hid); },
+            [&](auto o, const f32x16 &a) {
+                constexpr int O = decltype(o)::value;
+                if constexpr (O == 0) raw_density = a[0];
+                hb[O] = a;
+                if constexpr (VIEW_F32) hbf[O] = a; else nlr_pack1<false>(hbe[O], a);
+            });
+        if constexpr (HT > 0) {
+            f32x16 hh[HTA];
+            nlr_gemm<HT, BT * 4, 1, P_H1 & 1>(
+                tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H1, o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, BT>(a, f0, hb); },
+                [&](auto o, const f32x16 &a) { hh[decltype(o)::value] = nlr_act<true>(a); });
+            nlr_gemm<1, HT * 4, 1, P_H2 & 1>(
+                tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H2, o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, HTA>(a, f0, hh); },
+                [&](auto, const f32x16 &a) { lo = a; });
+        }
+    }
+    if (h == 0 && valid) {
+        const float x = raw_density + P.density_bias;
+        P.density[sample] = x > 20.0f ? x : log1pf(expf(x));
+    }
+    // ---- semantic / intensity outputs: rows [0,K) logits -> softmax, row int_row -> intensity.
+    // Per-sample heads are stored class-major ([K, M], [3, M]): one store instruction writes two 128-byte runs.
+    if constexpr (HT > 0) {
+        if (P.K > 0) {  // softmax over rows [0,K) of this column, split over the two lane halves
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (nlr_row(r, h) < (int)P.K) mx = fmaxf(mx, lo[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float e[16], s = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                e[r] = 0.0f;
+                if (nlr_row(r, h) < (int)P.K) {
+                    e[r] = expf(lo[r] - mx);
+                    s += e[r];
+                }
+            }
+            s += __shfl_xor(s, 32, 64);
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (nlr_row(r, h) < (int)P.K) P.sem[(size_t)nlr_row(r, h) * P.M + sample] = e[r] / s;
+            }
+        }
+        if (P.inten && valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (nlr_row(r, h) == (int)P.int_row) P.inten[sample] = lo[r];
+        }
+    }
+    if (P.rgb == nullptr) return;  // density/semantic/intensity only (uniform for the whole grid)
+
+    // ---- view MLP.  Layer 0 input = [bottleneck | enc]; layer 1 input = [x | bottleneck | enc] (skip concat,
+    // models.py:1227-1228); the 27 dir-encoding features ride as one extra zero-padded 32-feature input tile.
+    f32x16 out1;
+    if constexpr (!VIEW_F32) {
+        nlr_pack1<false>(hbe[BT], encf);
+        TileH x[WT], y[WT];
+        nlr_gemm<WT, (BT + 1) * 2, 1, P_V0 & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V0, o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
+                constexpr int G = decltype(g)::value;
+                nlr_mma_bf16(a, f0, hbe[G >> 1].f[G & 1]);
+            },
+            [&](auto o, const f32x16 &a) { nlr_pack1<true>(x[decltype(o)::value], a); });
+        nlr_gemm<WT, (WT + BT + 1) * 2, 1, P_V1 & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V1, o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
+                constexpr int G = decltype(g)::value;
+                if constexpr (G < 2 * WT) nlr_mma_bf16(a, f0, x[G >> 1].f[G & 1]);
+                else nlr_mma_bf16(a, f0, hbe[(G - 2 * WT) >> 1].f[G & 1]);
+            },
+            [&](auto o, const f32x16 &a) { nlr_pack1<true>(y[decltype(o)::value], a); });
+        for (uint32_t l = 2; l < P.depth; ++l) {
+            const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
+            nlr_gemm<WT, WT * 2, 1, P_VL & 1, true>(
+                tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
+                    constexpr int G = decltype(g)::value;
+                    nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
+                },
+                [&](auto o, const f32x16 &a) { nlr_pack1<true>(x[decltype(o)::value], a); });
+#pragma unroll
+            for (int t = 0; t < WT; ++t) y[t] = x[t];
+        }
+        nlr_gemm<1, WT * 2, 1, P_VL & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
+                constexpr int G = decltype(g)::value;
+                nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
+            },
+            [&](auto, const f32x16 &a) { out1 = a; });
+    } else {
+        hbf[BT] = encf;
+        f32x16 x[WT], y[WT];
+        nlr_gemm<WT, (BT + 1) * 4, 1, P_V0 & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V0, o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, BT + 1>(a, f0, hbf); },
+            [&](auto o, const f32x16 &a) { x[decltype(o)::value] = nlr_act<true>(a); });
+        nlr_gemm<WT, (WT + BT + 1) * 4, 1, P_V1 & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V1, o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
+                constexpr int G = decltype(g)::value;
+                if constexpr (G < 4 * WT) nlr_mma_f32<G, WT>(a, f0, x);
+                else nlr_mma_f32<G - 4 * WT, BT + 1>(a, f0, hbf);
+            },
+            [&](auto o, const f32x16 &a) { y[decltype(o)::value] = nlr_act<true>(a); });
+        for (uint32_t l = 2; l < P.depth; ++l) {
+            const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
+            nlr_gemm<WT, WT * 4, 1, P_VL & 1, true>(
+                tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, WT>(a, f0, y); },
+                [&](auto o, const f32x16 &a) { x[decltype(o)::value] = nlr_act<true>(a); });
+#pragma unroll
+            for (int t = 0; t < WT; ++t) y[t] = x[t];
+        }
+        nlr_gemm<1, WT * 4, 1, P_VL & 1>(
+            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
+            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, WT>(a, f0, y); },
+            [&](auto, const f32x16 &a) { out1 = a; });
+    }
+    if (h == 0 && valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float z = P.rgb_premul * out1[c] + P.rgb_bias;
+            const float sg = 1.0f / (1.0f + expf(-z));
+            P.rgb[(size_t)c * P.M + sample] = sg * (1.0f + 2.0f * P.rgb_padding) - P.rgb_padding;
+        }
+    }
+}
+
+
+// One explicit instance per translation unit (nlr_mlp_inst.hip is compiled once per (WT, HT, PREC) by the Makefile:
+// the fully unrolled GEMM chain is slow to compile, so the instances build in parallel).
+#define NLR_MLP_LAUNCH_NAME2(wt, ht, pr) nlr_mlp_launch_##wt##_##ht##_##pr
+#define NLR_MLP_LAUNCH_NAME(wt, ht, pr) NLR_MLP_LAUNCH_NAME2(wt, ht, pr)
+#define NLR_MLP_DECLARE(wt, ht, pr) void NLR_MLP_LAUNCH_NAME(wt, ht, pr)(const MlpParams &P, dim3 grid, hipStream_t st)

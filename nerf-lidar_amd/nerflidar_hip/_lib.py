@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerflidar_hip.so")
+LIB_PATH = os.environ.get("NLR_LIB_PATH") or os.path.join(_HERE, "libnerflidar_hip.so")  # override: diagnostic builds only
 
 NLR_MAX_LEVELS = 4
 NLR_MAX_VIEW_DEPTH = 16

@@ -195,10 +195,10 @@ class Model:
             h: Dict[str, torch.Tensor] = {"depth": new(n)}
             if want_history:
                 h.update(sdist=new(n, S + 1), tdist=new(n, S + 1), weights=new(n, S), density=new(n, S))
-                if li == len(samples) - 1:
-                    h["rgb"] = new(n, S, 3)
+                if li == len(samples) - 1:  # the library writes per-sample heads channel-/class-major
+                    h["rgb"] = new(3, n, S)
                     if K:
-                        h["semantic"] = new(n, S, K)
+                        h["semantic"] = new(K, n, S)
                     if self.config.use_intensity:
                         h["intensity"] = new(n, S)
             for k, t in h.items():
@@ -223,6 +223,11 @@ class Model:
             rc = _lib.lib().nlr_render_rays(self._handle, C.byref(rays), n, C.byref(cfg), C.byref(out),
                                             _lib.ptr(ws), ws.numel(), _lib.current_stream())
         _lib.check(rc, "nlr_render_rays")
+        if want_history:  # back to the reference's [N, S, C] layout (ZI/models.py:553-557)
+            last = hist[-1]
+            last["rgb"] = last["rgb"].permute(1, 2, 0)
+            if "semantic" in last:
+                last["semantic"] = last["semantic"].permute(1, 2, 0)
         return r, hist
 
     # -- reference-compatible call --------------------------------------------------------------

@@ -176,7 +176,9 @@ def test_composite(name):
     g = golden(name)
     n, S = g["density"].shape
     K = g["sem"].shape[-1]
-    ins = {k: cu(g[k]) for k in ("density", "tdist", "dirs", "rgbs", "sem", "intensity", "far")}
+    ins = {k: cu(g[k]) for k in ("density", "tdist", "dirs", "intensity", "far")}
+    ins["rgbs"] = cu(np.ascontiguousarray(g["rgbs"].transpose(2, 0, 1)))  # channel-major [3,N,S]
+    ins["sem"] = cu(np.ascontiguousarray(g["sem"].transpose(2, 0, 1)))    # class-major [K,N,S]
     origins = cu(np.zeros((n, 3), np.float32) + 0.25)
     out = _lib.NlrOut()
     res = {k: torch.empty(n, *sh, device=DEV) for k, sh in dict(rgb=(3,), depth=(), semantic=(K,), intensity=(), acc=(),
@@ -230,8 +232,8 @@ def test_mlp_level(name, precision):
     K = mc.nerf_mlp.class_num
     feat = torch.empty(KM * S, F, device=DEV)
     dens = torch.empty(KM, S, device=DEV)
-    rgb = torch.empty(KM, S, 3, device=DEV)
-    sem = torch.empty(KM, S, K, device=DEV)
+    rgb = torch.empty(3, KM, S, device=DEV)   # channel-major, as the library writes per-sample heads
+    sem = torch.empty(K, KM, S, device=DEV)   # class-major
     inten = torch.empty(KM, S, device=DEV) if mc.config.use_intensity else None
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
     rc = _lib.lib().nlr_mlp_level(model._handle, mc.num_levels - 1, C.byref(rays), _lib.ptr(tdist), KM, 7, 3, None, _lib.ptr(feat),
@@ -246,11 +248,11 @@ def test_mlp_level(name, precision):
     np.testing.assert_allclose(npy(feat), ref_feat, atol=2e-4, rtol=1e-4)
     # density: pre-activation is the feature error times the x1500 "trained-like" gain of density_layer.2 row 0
     np.testing.assert_allclose(npy(dens), g["density"], atol=5e-2, rtol=2e-3)
-    np.testing.assert_allclose(npy(sem), g["semantic"], atol=2e-3, rtol=1e-3)
+    np.testing.assert_allclose(npy(sem.permute(1, 2, 0)), g["semantic"], atol=2e-3, rtol=1e-3)
     if inten is not None:
         np.testing.assert_allclose(npy(inten), g["intensity"][..., 0], atol=1e-3, rtol=1e-3)
     rgb_tol = 1e-4 if precision == _lib.PREC_F32 else 2e-2  # bf16 view MLP (8 bits of mantissa per layer)
-    np.testing.assert_allclose(npy(rgb), g["rgb"], atol=rgb_tol, rtol=0)
+    np.testing.assert_allclose(npy(rgb.permute(1, 2, 0)), g["rgb"], atol=rgb_tol, rtol=0)
     # proposal network of level 0 on the same gaussians: same weights, a model view whose proposal level has the
     # NerfMLP sample count (weights do not depend on the sample count)
     import dataclasses
