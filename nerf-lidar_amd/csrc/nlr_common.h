@@ -47,6 +47,11 @@ struct GridParams {
     float scale[NLR_MAX_GRID_LEVELS];     // exp2f(l*S)*H-1 (cu:138)
     float gsize[NLR_MAX_GRID_LEVELS];     // grid_sizes[l] as float (grid.py:128-129,142)
     uint32_t dense[NLR_MAX_GRID_LEVELS];  // 1 when the dense stride walk never exceeds hsize
+    // Index mode per level, decided once on the host (the reference re-derives it per corner, gridencoder.cu:66-84):
+    //   0 dense: x + y*s + z*s*s, always < hsize (no modulo);  1 hashed with a power-of-two table: & (hsize-1);
+    //   2 generic: the reference's stride walk + modulo, corner by corner
+    uint32_t mode[NLR_MAX_GRID_LEVELS];
+    uint32_t step[NLR_MAX_GRID_LEVELS];   // s = resolution (+1 unless align_corners)
 };
 
 int nlr_fill_grid_params(GridParams *gp, const void *table, int table_dtype, const int32_t *offsets_host,
@@ -66,6 +71,30 @@ __device__ __forceinline__ uint32_t nlr_grid_index(uint32_t gridtype, uint32_t a
     if (stride <= hsize) { index += z * stride; stride *= step; }
     if (gridtype == 0 && stride > hsize) index = x ^ (y * 2654435761u) ^ (z * 805459861u);
     return index % hsize;
+}
+
+// Table indices of the 8 cell corners (corner c8: bit d set -> coordinate pg[d]+1), identical to calling
+// nlr_grid_index per corner but with the level's mode resolved once and the y/z terms shared between corners.
+template <int MODE>
+__device__ __forceinline__ void nlr_corner_idx(const GridParams &gp, uint32_t level, const uint32_t (&pg)[3], uint32_t (&idx)[8]) {
+    if (MODE == 0) {
+        const uint32_t s = gp.step[level];
+        const uint32_t y0 = pg[1] * s, z0 = pg[2] * s * s;
+        const uint32_t y1 = y0 + s, z1 = z0 + s * s;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) idx[c8] = (pg[0] + (c8 & 1)) + ((c8 & 2) ? y1 : y0) + ((c8 & 4) ? z1 : z0);
+    } else if (MODE == 1) {
+        const uint32_t mask = gp.hsize[level] - 1u;
+        const uint32_t y0 = pg[1] * 2654435761u, z0 = pg[2] * 805459861u;
+        const uint32_t y1 = y0 + 2654435761u, z1 = z0 + 805459861u;  // (g+1)*p == g*p + p  (mod 2^32)
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) idx[c8] = ((pg[0] + (c8 & 1)) ^ ((c8 & 2) ? y1 : y0) ^ ((c8 & 4) ? z1 : z0)) & mask;
+    } else {
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8)
+            idx[c8] = nlr_grid_index(gp.gridtype, gp.align_corners, gp.hsize[level], gp.res[level], pg[0] + (c8 & 1),
+                                     pg[1] + ((c8 >> 1) & 1), pg[2] + ((c8 >> 2) & 1));
+    }
 }
 
 __device__ __forceinline__ float nlr_wave_incl_scan_add(float v, int lane) {

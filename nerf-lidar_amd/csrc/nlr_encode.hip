@@ -64,11 +64,10 @@ template <>
 __device__ __forceinline__ float nlr_ld<__half>(const __half *p) { return __half2float(*p); }
 
 // Trilinear interpolation of C channels at one level (gridencoder.cu:137-197); acc += w_erf * value.
-template <typename T, int C>
-__device__ __forceinline__ void nlr_level_accum(const GridParams &gp, uint32_t level, const Gauss &g, float werf, float (&acc)[C]) {
+template <typename T, int C, int MODE>
+__device__ __forceinline__ void nlr_level_accum_m(const GridParams &gp, uint32_t level, const Gauss &g, float werf, float (&acc)[C]) {
     if ((g.x0 < 0 || g.x0 > 1) || (g.x1 < 0 || g.x1 > 1) || (g.x2 < 0 || g.x2 > 1)) return;  // zeros
     const T *grid = (const T *)gp.table + (size_t)gp.offset[level] * C;
-    const uint32_t hsize = gp.hsize[level], res = gp.res[level];
     const float scale = gp.scale[level];
     const float half = gp.align_corners ? 0.0f : 0.5f;
     float pos[3] = {fmaf(g.x0, scale, half), fmaf(g.x1, scale, half), fmaf(g.x2, scale, half)};
@@ -80,38 +79,34 @@ __device__ __forceinline__ void nlr_level_accum(const GridParams &gp, uint32_t l
         if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
     }
     uint32_t idx[8];
-    float w[8];
-#pragma unroll
-    for (int c8 = 0; c8 < 8; ++c8) {
-        float ww = 1.0f;
-        uint32_t pl[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if ((c8 >> d) & 1) {
-                ww *= pos[d];
-                pl[d] = pg[d] + 1;
-            } else {
-                ww *= 1 - pos[d];
-                pl[d] = pg[d];
-            }
-        }
-        w[c8] = ww;
-        idx[c8] = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pl[0], pl[1], pl[2]) * C;
-    }
+    nlr_corner_idx<MODE>(gp, level, pg, idx);
     float v[8][C];
 #pragma unroll
     for (int c8 = 0; c8 < 8; ++c8)
 #pragma unroll
-        for (int c = 0; c < C; ++c) v[c8][c] = nlr_ld<T>(grid + idx[c8] + c);
+        for (int c = 0; c < C; ++c) v[c8][c] = nlr_ld<T>(grid + (size_t)idx[c8] * C + c);
+    // corner weights in the reference's multiplication order ((wx * wy) * wz)
+    const float wx[2] = {1 - pos[0], pos[0]}, wy[2] = {1 - pos[1], pos[1]}, wz[2] = {1 - pos[2], pos[2]};
     float r[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) r[c] = 0.0f;
 #pragma unroll
-    for (int c8 = 0; c8 < 8; ++c8)
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const float w = (wx[c8 & 1] * wy[(c8 >> 1) & 1]) * wz[(c8 >> 2) & 1];
 #pragma unroll
-        for (int c = 0; c < C; ++c) r[c] = fmaf(w[c8], v[c8][c], r[c]);
+        for (int c = 0; c < C; ++c) r[c] = fmaf(w, v[c8][c], r[c]);
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] += r[c] * werf;
+}
+
+// `mode` is wave-uniform (a property of the level)
+template <typename T, int C>
+__device__ __forceinline__ void nlr_level_accum(const GridParams &gp, uint32_t level, const Gauss &g, float werf, float (&acc)[C]) {
+    const uint32_t mode = gp.mode[level];
+    if (mode == 0) nlr_level_accum_m<T, C, 0>(gp, level, g, werf, acc);
+    else if (mode == 1) nlr_level_accum_m<T, C, 1>(gp, level, g, werf, acc);
+    else nlr_level_accum_m<T, C, 2>(gp, level, g, werf, acc);
 }
 
 // models.py:976: erf(1 / clamp(sqrt(8 * std^2 * G^2), min=1e-10))

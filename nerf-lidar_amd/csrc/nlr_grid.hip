@@ -56,6 +56,12 @@ int nlr_fill_grid_params(GridParams *gp, const void *table, int table_dtype, con
         }
         if (gridtype == 0 && stride > gp->hsize[l]) dense = 0;
         gp->dense[l] = dense;
+        gp->step[l] = (uint32_t)step;
+        const uint32_t hs = gp->hsize[l];
+        const bool all3 = (step <= hs) && (step * step <= hs);  // the stride walk adds all three coordinates
+        if (all3 && step * step * step <= hs) gp->mode[l] = 0;                 // dense, index < hsize
+        else if (gridtype == 0 && (hs & (hs - 1)) == 0) gp->mode[l] = 1;       // hashed, power-of-two table
+        else gp->mode[l] = 2;
     }
     return NLR_OK;
 }
