@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference/NeRF_LiDAR/zipnerf"
 sys.path.insert(0, os.path.join(ROOT, "nerf-lidar_amd"))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 
 import numpy as np
 import torch
@@ -301,6 +302,25 @@ def gen_mlp_and_forward():
                  prop_density=pres["density"])
 
 
+from unet_fill import unet_fill  # noqa: E402  (tests/golden/unet_fill.py)
+
+
+def gen_unet():
+    print("UNet fixture (reference RD/unet)")
+    sys.path.insert(0, "/root/reference/NeRF_LiDAR/NeRF_Lidar_code/src")
+    from unet.unet_model import UNet as RefUNet
+    for tag, reg in (("logits", False), ("regression", True)):
+        m = RefUNet(n_channels=6, n_classes=2, bilinear=True, regression=reg).eval()
+        unet_fill(m, 7)
+        x = rnd(7, 30, (2, 6, 32, 64))
+        with torch.no_grad():
+            out = m(x)
+        if reg:
+            save(f"unet_{tag}", x=x, logits=out[0], reg=out[1])
+        else:
+            save(f"unet_{tag}", x=x, logits=out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -308,4 +328,5 @@ if __name__ == "__main__":
     gen_coord_render()
     gen_lidar()
     gen_mlp_and_forward()
+    gen_unet()
     print("done")
