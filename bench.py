@@ -74,9 +74,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2")
-    ap.add_argument("--precision", type=int, default=_lib.PREC_MIXED)
+    ap.add_argument("--precision", type=int, default=_lib.PREC_FAST)
     ap.add_argument("--log2-hashmap", type=int, default=None, help="shrink the hash tables (debug only)")
     ap.add_argument("--cpu-rays", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")

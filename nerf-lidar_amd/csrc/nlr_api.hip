@@ -17,7 +17,7 @@ void nlr_set_error(const char *fmt, ...) {
 extern "C" const char *nlr_last_error(void) { return g_err; }
 extern "C" int nlr_version(void) { return 100; }
 extern "C" const char *nlr_kernel_names(void) {
-    return "nlr_resample_kernel,nlr_prop_kernel,nlr_encode_kernel,nlr_direnc_kernel,nlr_mlp_kernel,nlr_composite_kernel";
+    return "nlr_resample_kernel,nlr_prop8_kernel,nlr_encode8_kernel,nlr_direnc_kernel,nlr_mlp_kernel,nlr_composite_kernel";
 }
 
 // ---- optional per-kernel event timing ---------------------------------------------------------------

@@ -113,6 +113,12 @@ __device__ __forceinline__ void nlr_level_accum(const GridParams &gp, uint32_t l
 __device__ __forceinline__ float nlr_erf_weight(float zs, float gsize) {
     return erff(1.0f / fmaxf(sqrtf((8.0f * (zs * zs)) * (gsize * gsize)), 1e-10f));
 }
+// The same weight with the level-independent part hoisted: 1/sqrt(8 std^2 G^2) = inv_s8 / G with
+// inv_s8 = 1/sqrt(8 std^2) computed once per multisample (differs from the reference's rounding order by a few
+// ulp of the erf ARGUMENT, i.e. <= 3e-7 of the weight; the clamp at 1e-10 maps to an argument cap of 1e10).
+__device__ __forceinline__ float nlr_erf_weight_fast(float inv_s8, float inv_g) {
+    return erff(fminf(inv_s8 * inv_g, 1e10f));
+}
 
 // ---------------------------------------------------------------------------------------------
 // NerfMLP level: one thread per (sample, grid level); blockIdx.y = level (level-major dispatch keeps
@@ -211,6 +217,127 @@ __global__ void __launch_bounds__(256) nlr_prop_kernel(CastParams cp, GridParams
     density[m] = x > 20.0f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20), models.py:1116
 }
 
+// =============================================================================================================
+// Multisample-parallel variants (sample_n <= 8): one lane per (sample, multisample), 8 lanes per sample.
+// Cone casting + contraction run ONCE per multisample (the (sample, level) mapping above repeats them per level),
+// every lane walks all grid levels with its 8*L gathers in flight, and the mean over the multisamples is a 3-step
+// butterfly inside each 8-lane group.  7/8 of the lanes are active for sample_n = 7.
+// =============================================================================================================
+__device__ __forceinline__ float nlr_group8_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+template <typename T, int C>
+__global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = cp.N * cp.S;
+    uint32_t m = gt >> 3;
+    const uint32_t j = gt & 7;
+    const bool in = m < M;
+    if (!in) m = M - 1;
+    const bool active = in && j < cp.n;
+    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    float o[3], d[3], bx[3], by[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = cp.origins[(size_t)ray * 3 + c];
+        d[c] = cp.directions[(size_t)ray * 3 + c];
+        bx[c] = cp.base_x[(size_t)ray * 3 + c];
+        by[c] = cp.base_y[(size_t)ray * 3 + c];
+    }
+    const float radius = cp.radii[ray];
+    const float t0 = cp.tdist[(size_t)ray * (cp.S + 1) + k], t1 = cp.tdist[(size_t)ray * (cp.S + 1) + k + 1];
+    Gauss g = nlr_cast_one(cp, ray, k, active ? j : 0, t0, t1, o, d, bx, by, radius);
+    if (!active) g.x0 = -1.0f;  // out of range -> contributes zeros
+    const float inv_s8 = 1.0f / sqrtf(8.0f * (g.zs * g.zs));
+    const float inv_n = 1.0f / (float)cp.n;
+    for (uint32_t l = 0; l < gp.L; ++l) {
+        const float werf = re_weights ? nlr_erf_weight_fast(inv_s8, 1.0f / gp.gsize[l]) : 1.0f;
+        float a[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) a[c] = 0.0f;
+        nlr_level_accum<T, C>(gp, l, g, werf, a);
+#pragma unroll
+        for (int c = 0; c < C; ++c) a[c] = nlr_group8_sum(a[c]);
+        if (in && j == (l & 7)) {  // spread the row stores over the lanes of the group
+            float *f = feat + (size_t)m * gp.L * C + l * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) f[c] = a[c] * inv_n;
+        }
+    }
+}
+
+// Proposal level: features as above, then the 64-unit density MLP split over the 8 lanes of the group (8 hidden
+// units per lane) and a final butterfly for the raw density.
+template <typename T, int C, int LMAX>
+__global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParams gp, PropMlpParams mp, int re_weights,
+                                                        float *__restrict__ density, float *__restrict__ feat_out) {
+    __shared__ float sw[64 * 16 + 128];  // w1 [64, F] | b1 [64] | w2 [64]
+    for (uint32_t i = threadIdx.x; i < 64 * mp.F; i += 256) sw[i] = mp.w1[i];
+    if (threadIdx.x < 64) {
+        sw[64 * mp.F + threadIdx.x] = mp.b1[threadIdx.x];
+        sw[64 * mp.F + 64 + threadIdx.x] = mp.w2[threadIdx.x];
+    }
+    __syncthreads();
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = cp.N * cp.S;
+    uint32_t m = gt >> 3;
+    const uint32_t j = gt & 7;
+    const bool in = m < M;
+    if (!in) m = M - 1;
+    const bool active = in && j < cp.n;
+    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    float o[3], d[3], bx[3], by[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = cp.origins[(size_t)ray * 3 + c];
+        d[c] = cp.directions[(size_t)ray * 3 + c];
+        bx[c] = cp.base_x[(size_t)ray * 3 + c];
+        by[c] = cp.base_y[(size_t)ray * 3 + c];
+    }
+    const float radius = cp.radii[ray];
+    const float t0 = cp.tdist[(size_t)ray * (cp.S + 1) + k], t1 = cp.tdist[(size_t)ray * (cp.S + 1) + k + 1];
+    Gauss g = nlr_cast_one(cp, ray, k, active ? j : 0, t0, t1, o, d, bx, by, radius);
+    if (!active) g.x0 = -1.0f;
+    const float inv_s8 = 1.0f / sqrtf(8.0f * (g.zs * g.zs));
+    const float inv_n = 1.0f / (float)cp.n;
+    float feat[LMAX * C];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        float a[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) a[c] = 0.0f;
+        if (l < (int)gp.L) {
+            const float werf = re_weights ? nlr_erf_weight_fast(inv_s8, 1.0f / gp.gsize[l]) : 1.0f;
+            nlr_level_accum<T, C>(gp, l, g, werf, a);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) feat[l * C + c] = nlr_group8_sum(a[c]) * inv_n;  // every lane of the group gets the mean
+    }
+    if (feat_out && in && j == 0)
+        for (uint32_t i = 0; i < mp.F; ++i) feat_out[(size_t)m * mp.F + i] = feat[i];
+    // hidden unit hu = 8*hh + j: the 8 lanes of a group read 8 consecutive weight rows from the LDS copy (row stride
+    // F floats -> at most 2-way bank conflicts), the 8 groups of a wave read the same addresses (broadcast)
+    float part = 0.0f;
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) {
+        const uint32_t hu = hh * 8 + j;
+        float a = sw[64 * mp.F + hu];
+#pragma unroll
+        for (int i = 0; i < LMAX * C; ++i)
+            if (i < (int)mp.F) a = fmaf(sw[hu * mp.F + i], feat[i], a);
+        part = fmaf(sw[64 * mp.F + 64 + hu], fmaxf(a, 0.0f), part);
+    }
+    const float raw = nlr_group8_sum(part) + mp.b2;
+    if (in && j == 0) {
+        const float x = raw + mp.density_bias;
+        density[m] = x > 20.0f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20), models.py:1116
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist, const float *rand_deg, uint32_t N,
                          uint32_t S, uint32_t n, uint32_t mloops, float std_scale) {
@@ -241,6 +368,28 @@ int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist
 
 int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, hipStream_t st) {
     const uint32_t M = cp.N * cp.S;
+    if (cp.n <= 8) {  // multisample-parallel mapping
+        dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
+#define NLR_ENC8(T, C) hipLaunchKernelGGL((nlr_encode8_kernel<T, C>), grid8, block8, 0, st, cp, gp, re_weights, feat)
+        if (gp.table_dtype == 0) {
+            switch (gp.C) {
+                case 1: NLR_ENC8(float, 1); break;
+                case 2: NLR_ENC8(float, 2); break;
+                case 4: NLR_ENC8(float, 4); break;
+                default: NLR_ENC8(float, 8); break;
+            }
+        } else {
+            switch (gp.C) {
+                case 1: NLR_ENC8(__half, 1); break;
+                case 2: NLR_ENC8(__half, 2); break;
+                case 4: NLR_ENC8(__half, 4); break;
+                default: NLR_ENC8(__half, 8); break;
+            }
+        }
+#undef NLR_ENC8
+        NLR_LAUNCH_CHECK("nlr_encode8_kernel");
+        return NLR_OK;
+    }
     dim3 grid((M + 255) / 256, gp.L), block(256);
 #define NLR_ENC(T, C) hipLaunchKernelGGL((nlr_encode_kernel<T, C>), grid, block, 0, st, cp, gp, re_weights, feat)
     if (gp.table_dtype == 0) {
@@ -274,6 +423,19 @@ int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1,
     mp.density_bias = density_bias;
     mp.F = gp.L * gp.C;
     NLR_CHECK_ARG(mp.F <= 16, "proposal MLP: L*C = %u > 16 features is outside the fused proposal kernel", mp.F);
+    if (cp.n <= 8) {
+        dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
+#define NLR_PROP8(T, C, LM) hipLaunchKernelGGL((nlr_prop8_kernel<T, C, LM>), grid8, block8, 0, st, cp, gp, mp, re_weights, density, feat_out)
+        const bool f32t = gp.table_dtype == 0;
+        if (gp.C == 1 && gp.L <= 8) { if (f32t) NLR_PROP8(float, 1, 8); else NLR_PROP8(__half, 1, 8); }
+        else if (gp.C == 1) { if (f32t) NLR_PROP8(float, 1, 16); else NLR_PROP8(__half, 1, 16); }
+        else if (gp.C == 2) { if (f32t) NLR_PROP8(float, 2, 8); else NLR_PROP8(__half, 2, 8); }
+        else if (gp.C == 4 && gp.L <= 4) { if (f32t) NLR_PROP8(float, 4, 4); else NLR_PROP8(__half, 4, 4); }
+        else NLR_FAIL(NLR_ERR_UNSUPPORTED, "proposal MLP: grid L=%u C=%u not supported by the fused proposal kernel", gp.L, gp.C);
+#undef NLR_PROP8
+        NLR_LAUNCH_CHECK("nlr_prop8_kernel");
+        return NLR_OK;
+    }
     dim3 grid((M + 255) / 256), block(256);
 #define NLR_PROP(T, C, LM) hipLaunchKernelGGL((nlr_prop_kernel<T, C, LM>), grid, block, 0, st, cp, gp, mp, re_weights, density, feat_out)
     const bool f32 = gp.table_dtype == 0;

@@ -56,11 +56,12 @@ struct Tape {
     int cur, total, tid, lane;
     __device__ __forceinline__ uint4 *buf(int c) const { return lds + (c % NLR_NBUF) * NLR_CHUNK_SLOTS; }
     __device__ __forceinline__ void load(uint4 (&r)[NLR_CHUNK_LOADS], int c) {
-        // uniform base + 32-bit per-lane byte offset: one v_add per load instead of a 64-bit add chain
-        const char *b = reinterpret_cast<const char *>(base);
-        const uint32_t off = ((uint32_t)c * NLR_CHUNK_SLOTS + (uint32_t)tid) * 16u;
+        // wave-uniform chunk base (SALU) + one 32-bit per-lane byte offset: the loads take the
+        // `global_load_dwordx4 v, v_off, s[base:base+1]` form and need no per-load VALU address arithmetic
+        const char *cb = reinterpret_cast<const char *>(base) + (size_t)c * (NLR_CHUNK_SLOTS * 16);
+        const uint32_t voff = (uint32_t)tid * 16u;
 #pragma unroll
-        for (int i = 0; i < NLR_CHUNK_LOADS; ++i) r[i] = *reinterpret_cast<const uint4 *>(b + (off + (uint32_t)i * 4096u));
+        for (int i = 0; i < NLR_CHUNK_LOADS; ++i) r[i] = *reinterpret_cast<const uint4 *>(cb + i * 4096 + voff);
     }
     __device__ __forceinline__ void store(const uint4 (&r)[NLR_CHUNK_LOADS], int c) {
         uint4 *q = buf(c) + tid;
