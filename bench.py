@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--precision", type=int, default=_lib.PREC_FAST)
     ap.add_argument("--log2-hashmap", type=int, default=None, help="shrink the hash tables (debug only)")
-    ap.add_argument("--cpu-rays", type=int, default=2048)
+    ap.add_argument("--cpu-rays", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -142,6 +142,16 @@ def main():
         fl_launch = 2.0 * nflops.macs_per_sample(mc.nerf_mlp) * n_rays * S_last
         mlp_s = kern["mlp"] * 1e-3
         achieved = fl_launch / mlp_s / 1e12 if mlp_s > 0 else 0.0
+        # HBM traffic of the dominant kernel per launch: not measurable from inside the process; taken from the last
+        # rocprofv3 --pmc run of scripts/pmc_traffic.sh (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if committed.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            for k, v in tj.items():
+                if "nlr_mlp_kernel" in k and world == 1 and args.workload == "C2":
+                    traffic = v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
+        except Exception:
+            pass
         out = {
             "metric": "LiDAR rays/sec @128 samples/ray, 8x256 MLP; depth L1 vs reference",
             "value": rays_total / dt,
@@ -165,7 +175,8 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "roofline": {"kernel": "nlr_mlp_kernel", "bound": "mfma", "achieved": achieved,
                          "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None},
+                         "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "bytes per launch from profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = host_cores()

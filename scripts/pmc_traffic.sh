@@ -1,0 +1,28 @@
+#!/bin/bash
+# HBM traffic of the render kernels: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md, HBM section).
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
+mkdir -p $OUT
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python3 - <<'PY'
+import csv, glob, collections, json
+res = collections.defaultdict(dict)
+for d in ("fetch", "write", "l2"):
+    for f in glob.glob(f"gpurun_out/pmc_traffic/{d}/**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            acc[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in acc.items():
+            if "nlr_" in k:
+                res[k][c] = sum(v) / len(v)
+for k, v in res.items():
+    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads half of a wide coalesced stream -> doubled
+    if "FETCH_SIZE" in v: v["hbm_read_bytes_corrected"] = v["FETCH_SIZE"] * 1024 * 2
+    if "WRITE_SIZE" in v: v["hbm_write_bytes"] = v["WRITE_SIZE"] * 1024
+    if "TCC_HIT_sum" in v: v["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    print(k, json.dumps(v))
+json.dump(res, open("gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
+PY
