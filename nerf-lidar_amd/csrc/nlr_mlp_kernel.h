@@ -47,7 +47,9 @@ __device__ __forceinline__ int nlr_row(int r, int h) { return (r & 3) + 8 * (r >
 #define NLR_CHUNK_SLOTS (NLR_CHUNK_FRAGS * 64)   // uint4 slots per chunk
 #define NLR_CHUNK_LOADS (NLR_CHUNK_SLOTS / 256)  // 16-byte loads per thread per chunk
 #define NLR_NBUF 3
+#ifndef NLR_PF
 #define NLR_PF 8                                 // fragment read-ahead (register ring)
+#endif
 struct Tape {
     const uint4 *__restrict__ base;
     uint4 *lds;  // [NLR_NBUF][NLR_CHUNK_SLOTS]
@@ -445,7 +447,26 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 else nlr_mma_bf16(a, f0, hbe[(G - 2 * WT) >> 1].f[G & 1]);
             },
             [&](auto o, const f32x16 &a) { nlr_pack1<true>(y[decltype(o)::value], a); });
-        for (uint32_t l = 2; l < P.depth; ++l) {
+        // hidden layers 2..D-1, two per iteration (y -> x -> y) so that no tile copies are needed
+        uint32_t l = 2;
+        for (; l + 1 < P.depth; l += 2) {
+            const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
+            nlr_gemm<WT, WT * 2, 1, P_VL & 1, true>(
+                tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
+                    constexpr int G = decltype(g)::value;
+                    nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
+                },
+                [&](auto o, const f32x16 &a) { nlr_pack1<true>(x[decltype(o)::value], a); });
+            nlr_gemm<WT, WT * 2, 1, P_VL & 1, true>(
+                tp, [&](auto o) { return nlr_bias_tile(bl + WT * 32, o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
+                    constexpr int G = decltype(g)::value;
+                    nlr_mma_bf16(a, f0, x[G >> 1].f[G & 1]);
+                },
+                [&](auto o, const f32x16 &a) { nlr_pack1<true>(y[decltype(o)::value], a); });
+        }
+        if (l < P.depth) {  // odd number of hidden layers: one more, result moved back into y
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
             nlr_gemm<WT, WT * 2, 1, P_VL & 1, true>(
                 tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
