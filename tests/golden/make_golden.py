@@ -34,7 +34,7 @@ import torch
 import torch.nn as nn
 
 from oracle import nlr_oracle as orc
-from nerflidar_hip import config as nconfig, lidar as nlidar, weights as nweights, synth
+from nerflidar_hip import camera as ncamera, config as nconfig, lidar as nlidar, weights as nweights, synth
 
 
 # ---------------------------------------------------------------------------- stubs
@@ -60,6 +60,8 @@ _stub("pyquaternion", Quaternion=object)
 sk = _stub("skimage")
 sk.metrics = _stub("skimage.metrics", structural_similarity=None, peak_signal_noise_ratio=None)
 _stub("cv2")
+absl = _stub("absl")
+absl.flags = _stub("absl.flags", DEFINE_multi_string=lambda *a, **k: None, DEFINE_string=lambda *a, **k: None, FLAGS=types.SimpleNamespace())
 
 
 class RefGridEncoder(nn.Module):
@@ -305,6 +307,36 @@ def gen_mlp_and_forward():
 from unet_fill import unet_fill  # noqa: E402  (tests/golden/unet_fill.py)
 
 
+def gen_camera():
+    """Config C3: camera rays through the reference's pixels_to_rays, then the reference forward (64 + 128 samples)."""
+    print("camera fixtures (C3)")
+    from internal import camera_utils as rcam
+    W, H, f = 64, 48, 50.0
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1.0]])
+    c2w = np.concatenate([nlidar.seeded_rotation(17), synth.uniform(0, 9300, (3, 1), -0.02, 0.02).astype(np.float64)], axis=1)
+    px, py = np.meshgrid(np.arange(W), np.arange(0, H, 8), indexing="xy")
+    px, py = px.reshape(-1).astype(np.float64), py.reshape(-1).astype(np.float64)
+    o, d, v, r, ip, bx, by = rcam.pixels_to_rays(px, py, np.linalg.inv(K), c2w)
+    save("fn_camera_rays", pix_x=px, pix_y=py, K=K, c2w=c2w, origins=o, directions=d, viewdirs=v, radii=r, imageplane=ip,
+         base_x=bx, base_y=by)
+    mc = nconfig.workload("C3", 15)
+    sd_np = nweights.synth_state_dict(mc, seed=2, trained_like=True)
+    model = build_ref_model(mc, sd_np)
+    batch_np = ncamera.synthetic_camera_batch(width=W, height=H, focal=f, seed=0, rows=np.arange(0, H, 8))
+    for k_, ref_ in (("origins", o), ("directions", d), ("radii", r), ("base_x", bx), ("base_y", by)):
+        assert np.allclose(batch_np[k_], ref_, atol=1e-6), k_
+    batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    with torch.no_grad():
+        rend, hist = model(False, batch, train_frac=1.0, compute_extras=True, zero_glo=True)
+    out = {"out_" + k: v for k, v in rend[-1].items() if not k.startswith("ray_")}
+    for lvl, h in enumerate(hist):
+        for k in ("sdist", "weights", "tdist"):
+            out[f"hist{lvl}_{k}"] = h[k][:24]
+        out[f"lvl{lvl}_depth"] = rend[lvl]["depth"]
+    save("camfwd_C3", workload=np.array("C3"), log2_hashmap=np.array(15), seed=np.array(2), trained_like=np.array(1),
+         cam=np.array([W, H, f]), rows=np.arange(0, H, 8), **out)
+
+
 def gen_unet():
     print("UNet fixture (reference RD/unet)")
     sys.path.insert(0, "/root/reference/NeRF_LiDAR/NeRF_Lidar_code/src")
@@ -329,4 +361,5 @@ if __name__ == "__main__":
     gen_lidar()
     gen_mlp_and_forward()
     gen_unet()
+    gen_camera()
     print("done")

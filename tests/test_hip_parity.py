@@ -309,6 +309,51 @@ def test_model_forward(name, precision):
         gate("rgb", npy(r["rgb"]), g["out_rgb"], 2e-3, 3e-2)  # bf16 view MLP: 8 mantissa bits per layer, 8 layers
 
 
+def test_camera_forward_c3():
+    """BASELINE config 3 (camera novel view, hierarchical 64 + 128): orthonormal image-plane bases, per-ray radii."""
+    from nerflidar_hip import camera as ncamera
+    from nerflidar_hip.models import Model
+    g = golden("camfwd_C3")
+    mc = nconfig.workload("C3", int(g["log2_hashmap"]))
+    sd = nweights.synth_state_dict(mc, seed=int(g["seed"]), trained_like=True)
+    W, H, f = g["cam"]
+    b = ncamera.synthetic_camera_batch(width=int(W), height=int(H), focal=float(f), seed=0, rows=g["rows"])
+    model = Model(mc, sd, device=DEV, precision=_lib.PREC_FAST)
+    rend, hist = model(False, {k: cu(v) for k, v in b.items()}, 1.0, True)
+    r = rend[-1]
+    assert np.abs(npy(r["depth"]) - g["out_depth"]).mean() <= 1e-3
+    np.testing.assert_array_equal(npy(r["semantic"]).argmax(-1), g["out_semantic"].argmax(-1))
+    assert np.abs(npy(r["rgb"]) - g["out_rgb"]).mean() <= 2e-3
+    for lvl in range(mc.num_levels):
+        assert np.abs(npy(hist[lvl]["sdist"][:24]) - g[f"hist{lvl}_sdist"]).mean() <= 1e-5
+
+
+def test_random_sampling_against_oracle():
+    """rand=True (training-time jitter, stepfun.py:211-216, render.py:149-150) with caller-provided uniform draws:
+    the HIP path against the pinned oracle fed the same draws."""
+    from nerflidar_hip.models import Model
+    mc = nconfig.workload("REF", 14)
+    sd = nweights.synth_state_dict(mc, seed=4, trained_like=True)
+    batch_np = nlidar.synthetic_sweep(width=16, seed=4, beams=nlidar.LIDAR_ANGLES[::8])
+    n = batch_np["origins"].shape[0]
+    rng = np.random.default_rng(0)
+    S = mc.level_samples()
+    rj = [rng.random((n, 1)).astype(np.float32) for _ in S]
+    rd = [rng.random((n, s, 7)).astype(np.float32) for s in S]
+    model = Model(mc, sd, device=DEV, precision=_lib.PREC_F32)
+    r, hist = model.render_rays({k: cu(v) for k, v in batch_np.items()}, want_history=True,
+                                rand_jitter=[cu(x) for x in rj], rand_deg=[cu(x) for x in rd])
+    ref, rh = orc.model_forward(sd, mc, {k: T(v) for k, v in batch_np.items()}, rand_jitter=[T(x) for x in rj],
+                                rand_deg=[T(x) for x in rd])
+    for lvl in range(mc.num_levels):
+        assert np.abs(npy(hist[lvl]["sdist"]) - rh[lvl]["sdist"].numpy()).mean() <= 1e-5
+    assert np.abs(npy(r["depth"]) - ref[-1]["depth"].numpy()).mean() <= 1e-3
+    np.testing.assert_array_equal(npy(r["semantic"]).argmax(-1), ref[-1]["semantic"].numpy().argmax(-1))
+    # and the draws matter: a deterministic render differs
+    r0, _ = model.render_rays({k: cu(v) for k, v in batch_np.items()})
+    assert np.abs(npy(r0["depth"]) - npy(r["depth"])).max() > 0
+
+
 def test_render_image_driver_and_labels():
     """render_image (models.py:1379-1507) chunking == one-shot; labels/points post-step (render_lidar.py:142-161)."""
     from nerflidar_hip.models import render_image

@@ -111,6 +111,30 @@ def test_lidar_batch():
     np.testing.assert_allclose(np.linalg.norm(b["viewdirs"], axis=-1), 1 / np.sqrt(d.shape[0]), rtol=1e-5)
 
 
+def test_camera_rays():
+    """Config C3 input producer: nerflidar_hip.camera (product host code) against the reference's pixels_to_rays."""
+    from nerflidar_hip import camera as ncamera
+    g = golden("fn_camera_rays")
+    out = ncamera.pixels_to_rays(g["pix_x"], g["pix_y"], np.linalg.inv(g["K"]), g["c2w"])
+    for got, k in zip(out, ("origins", "directions", "viewdirs", "radii", "imageplane", "base_x", "base_y")):
+        np.testing.assert_allclose(got, g[k], rtol=1e-12, atol=1e-14, err_msg=k)
+
+
+def test_model_forward_camera_c3():
+    """Whole forward on a camera batch (orthonormal base_x/base_y, per-ray radii), hierarchical (64 + 128) levels."""
+    from nerflidar_hip import camera as ncamera
+    g = golden("camfwd_C3")
+    mc = nconfig.workload("C3", int(g["log2_hashmap"]))
+    sd = nweights.synth_state_dict(mc, seed=int(g["seed"]), trained_like=True)
+    W, H, f = g["cam"]
+    b = ncamera.synthetic_camera_batch(width=int(W), height=int(H), focal=float(f), seed=0, rows=g["rows"])
+    rend, hist = orc.model_forward(sd, mc, {k: T(v) for k, v in b.items()})
+    for k in [k for k in g if k.startswith("out_")]:
+        close(rend[-1][k[4:]], g[k], atol=2e-5, rtol=1e-4)
+    for lvl in range(mc.num_levels):
+        close(hist[lvl]["sdist"][:24], g[f"hist{lvl}_sdist"], atol=2e-5, rtol=1e-4)
+
+
 def test_grid_numpy_twin_matches_c():
     """The C restatement of kernel_grid against an independently written numpy twin."""
     mc = nconfig.workload("REF", 12)
