@@ -229,6 +229,20 @@ int nlr_composite_level(const float *density, const float *tdist, const float *d
                         float scale_factor, float *weights, const NlrOut *out, float *level_depth,
                         void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (5) Renderer output -> ray-drop UNet input.  Replaces LaserScan.do_range_projection
+ *     (NeRF_Lidar_code/src/lidar_utils.py:215-282): spherical projection into an H x W range image where the NEAREST
+ *     point of a pixel wins (the reference sorts far->near and scatters).  points are float64 [N,3] in the LiDAR
+ *     frame (what nerf2world.py:22-38 produces); semantic [N] f32 / rgb [N,3] f32 may be NULL.  Outputs (any may be
+ *     NULL): proj_range [H,W] (-1 = empty), proj_xyz [H,W,3], proj_semantic [H,W], proj_rgb [H,W,3], proj_idx [H,W]
+ *     (-1 = empty), proj_mask [H,W] = (proj_idx > 0) as in the reference.
+ * ------------------------------------------------------------------------------------------ */
+size_t nlr_range_workspace_bytes(uint32_t H, uint32_t W);
+int nlr_range_project(const double *points, const float *semantic, const float *rgb, uint32_t N, uint32_t H, uint32_t W,
+                      float fov_up_deg, float fov_down_deg, void *workspace, size_t workspace_bytes, float *proj_range,
+                      float *proj_xyz, float *proj_semantic, float *proj_rgb, int32_t *proj_idx, float *proj_mask,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

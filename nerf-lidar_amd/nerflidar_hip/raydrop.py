@@ -166,15 +166,37 @@ def train_step(model: UNet, optim, vgg_loss: VGGLoss, img, gt_mask, gt_range, vg
     return loss.detach(), vl.detach()
 
 
-def range_features(depth, labels, rgb, scale_factor: float, max_range: float = 100.0):
-    """Renderer output ([H,W] depth in scene units, labels, [H,W,3] rgb) -> UNet input [1,6,H,W]:
-    [log-range, semantic, rgb x3, local range variance] as Generate_feature.py:144-167 stacks them
-    (log2(r+1)/6.5 normalisation and a +-2-column variance of lidar_utils.py:348-363).  Rays are already on the
-    beam x azimuth grid here, so no spherical re-projection / painter's scatter is needed."""
-    r = (depth / scale_factor).clamp(max=max_range)
-    lr = torch.log2(r + 1) / 6.5
-    pad = F.pad(lr[None, None], (2, 2, 0, 0), mode="circular")[0, 0]
-    win = torch.stack([pad[:, i:i + lr.shape[1]] for i in range(5)], 0)
-    var = win.var(0, unbiased=False)
-    feats = torch.stack([lr, labels.float() / 19.0, rgb[..., 0], rgb[..., 1], rgb[..., 2], var], 0)
-    return feats[None]
+def range_projection(points, semantic=None, rgb=None, H=32, W=1024, fov_up=10.67, fov_down=-30.67):
+    """LaserScan.do_range_projection on the GPU (libnerflidar_hip.so `nlr_range_project`; no CPU fallback).
+    points [N,3] float64 CUDA tensor in the LiDAR frame; returns dict of [H,W,...] CUDA tensors."""
+    import ctypes as C
+    from . import _lib
+    if not points.is_cuda:
+        raise RuntimeError("points must be a CUDA tensor")
+    pts = points.double().contiguous()
+    n, dev = pts.shape[0], pts.device
+    sem = None if semantic is None else semantic.float().contiguous()
+    col = None if rgb is None else rgb.float().contiguous()
+    out = dict(proj_range=torch.empty(H, W, device=dev), proj_xyz=torch.empty(H, W, 3, device=dev),
+               proj_semantic=torch.empty(H, W, device=dev), proj_rgb=torch.empty(H, W, 3, device=dev),
+               proj_idx=torch.empty(H, W, device=dev, dtype=torch.int32), proj_mask=torch.empty(H, W, device=dev))
+    L = _lib.lib()
+    ws = torch.empty(L.nlr_range_workspace_bytes(H, W), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.nlr_range_project(_lib.ptr(pts), _lib.ptr(sem), _lib.ptr(col), n, H, W, float(fov_up), float(fov_down), _lib.ptr(ws),
+                                 ws.numel(), _lib.ptr(out["proj_range"]), _lib.ptr(out["proj_xyz"]), _lib.ptr(out["proj_semantic"]),
+                                 _lib.ptr(out["proj_rgb"]), _lib.ptr(out["proj_idx"]), _lib.ptr(out["proj_mask"]), _lib.current_stream())
+    _lib.check(rc, "nlr_range_project")
+    return out
+
+
+def unet_features(proj, var=True):
+    """Stack the UNet input as Generate_feature.py:44-49,161-166 does: [log-range, semantic, rgb x3, (variance over the
+    4-column window of real_to_var(size=2))] -> [1, F, H, W]."""
+    real = proj["proj_range"]
+    lr = torch.clamp(torch.log2(torch.where(real < 0, torch.zeros_like(real), real) + 0.0001 + 1) / 6.5, 0, 1)
+    feats = [lr, proj["proj_semantic"], proj["proj_rgb"][..., 0], proj["proj_rgb"][..., 1], proj["proj_rgb"][..., 2]]
+    if var:
+        win = torch.stack([torch.roll(lr, i, dims=1) for i in range(-2, 2)], dim=-1)
+        feats.append(win.var(dim=-1, unbiased=False))
+    return torch.stack(feats, 0)[None]

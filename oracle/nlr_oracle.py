@@ -500,3 +500,46 @@ def render_chunked(sd_np, mc, batch, chunk=4096, **kw):
         r, _ = model_forward(sd_np, mc, cb, encoders=encoders, sd_t=sd_t, **kw)
         outs.append(r[-1])
     return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+
+
+# --------------------------------------------------------------------------------------------
+# f-2  point cloud -> range image (NeRF_Lidar_code/src/lidar_utils.py:215-282; Generate_feature.py:14-55;
+#      real_to_var lidar_utils.py:348-363)
+# --------------------------------------------------------------------------------------------
+def range_projection(points, semantic=None, rgb=None, H=32, W=1024, fov_up=10.67, fov_down=-30.67):
+    """numpy (float64) restatement of LaserScan.do_range_projection: far -> near scatter, nearest point wins."""
+    points = np.asarray(points)
+    n = points.shape[0]
+    semantic = np.zeros(n, np.float32) if semantic is None else np.asarray(semantic)
+    rgb = np.zeros((n, 3), np.float32) if rgb is None else np.asarray(rgb)
+    fu, fd = fov_up / 180.0 * np.pi, fov_down / 180.0 * np.pi
+    fov = abs(fd) + abs(fu)
+    depth = np.linalg.norm(points, 2, axis=1)
+    yaw = -np.arctan2(points[:, 1], points[:, 0])
+    pitch = np.arcsin(points[:, 2] / depth)
+    px = np.floor(0.5 * (yaw / np.pi + 1.0) * W)
+    py = np.floor((1.0 - (pitch + abs(fd)) / fov) * H)
+    px = np.maximum(0, np.minimum(W - 1, px)).astype(np.int32)
+    py = np.maximum(0, np.minimum(H - 1, py)).astype(np.int32)
+    order = np.argsort(depth, kind="stable")[::-1]
+    out = dict(proj_range=np.full((H, W), -1, np.float32), proj_xyz=np.full((H, W, 3), -1, np.float32),
+               proj_semantic=np.full((H, W), -1, np.float32), proj_rgb=np.zeros((H, W, 3), np.float32),
+               proj_idx=np.full((H, W), -1, np.int32))
+    out["proj_range"][py[order], px[order]] = depth[order]
+    out["proj_xyz"][py[order], px[order]] = points[order]
+    out["proj_semantic"][py[order], px[order]] = semantic[order]
+    out["proj_rgb"][py[order], px[order]] = rgb[order]
+    out["proj_idx"][py[order], px[order]] = np.arange(n)[order]
+    out["proj_mask"] = (out["proj_idx"] > 0).astype(np.float32)
+    return out
+
+
+def log_range(real):
+    """pcs2img(log=True), Generate_feature.py:44-49."""
+    real = np.where(real < 0, 0, real) + 0.0001
+    return np.clip(np.log2(real + 1) / 6.5, 0, 1)
+
+
+def real_to_var(real, size=1):
+    """lidar_utils.py:348-363 (sic: the window is range(-size, size), i.e. 2*size columns)."""
+    return np.var(np.stack([np.roll(real, i, axis=1) for i in range(-size, size)], axis=-1), axis=-1)

@@ -337,6 +337,28 @@ def gen_camera():
          cam=np.array([W, H, f]), rows=np.arange(0, H, 8), **out)
 
 
+def gen_range_image():
+    """f-2: the reference's LaserScan projection + pcs2img normalisation + real_to_var on a synthetic point cloud."""
+    print("range image fixture (reference RD/lidar_utils, Generate_feature)")
+    sys.path.insert(0, "/root/reference/NeRF_LiDAR/NeRF_Lidar_code/src")
+    import lidar_utils as rdl
+    n = 6000
+    d = nlidar.get_directions(nlidar.LIDAR_ANGLES, np.linspace(270, -90, n // 32) / 180 * np.pi)[:n].astype(np.float64)
+    rr = synth.uniform(3, 50, (d.shape[0],), 1.0, 60.0).astype(np.float64)
+    pts = d * rr[:, None] + synth.uniform(3, 51, d.shape, -0.01, 0.01)
+    pts = np.concatenate([pts, pts[:500] * 1.7, pts[100:300] * 0.5], 0)   # several points per pixel, nearer + farther
+    sem = np.floor(synth.uniform(3, 52, (pts.shape[0],), 0, 19)).astype(np.float32)
+    rgb = synth.uniform(3, 53, (pts.shape[0], 3), 0, 1)
+    real, psem, pmask, prgb, pxyz = rdl.point_cloud_to_range_image(pts, True, H=32, W=256, semantic=sem, rgb=rgb, return_semantic=True,
+                                                                   return_mask=True, return_points=True)
+    scan = rdl.LaserScan(H=32, W=256, fov_up=10.67, fov_down=-30.67)
+    scan.set_points(pts, semantic=sem, rgb=rgb)
+    scan.do_range_projection()
+    lr = np.clip(np.log2(np.where(real < 0, 0, real) + 0.0001 + 1) / 6.5, 0, 1)
+    save("fn_range_image", points=pts, semantic=sem, rgb=rgb, proj_range=real, proj_semantic=psem, proj_mask=pmask, proj_rgb=prgb,
+         proj_xyz=pxyz, proj_idx=scan.proj_idx, log_range=lr, var2=rdl.real_to_var(lr, size=2))
+
+
 def gen_unet():
     print("UNet fixture (reference RD/unet)")
     sys.path.insert(0, "/root/reference/NeRF_LiDAR/NeRF_Lidar_code/src")
@@ -362,4 +384,5 @@ if __name__ == "__main__":
     gen_mlp_and_forward()
     gen_unet()
     gen_camera()
+    gen_range_image()
     print("done")

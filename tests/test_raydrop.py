@@ -47,10 +47,39 @@ def test_train_step_cpu_small():
     assert torch.isfinite(l0) and torch.isfinite(l1)
 
 
-def test_range_features_shape():
-    d = torch.rand(32, 64) * 0.4
-    f = raydrop.range_features(d, torch.randint(0, 19, (32, 64)), torch.rand(32, 64, 3), 1 / 250)
-    assert f.shape == (1, 6, 32, 64) and torch.isfinite(f).all()
+def test_range_projection_oracle_matches_reference():
+    """f-2 oracle (numpy restatement) against the reference's LaserScan.do_range_projection / pcs2img / real_to_var."""
+    from oracle import nlr_oracle as orc
+    g = golden("fn_range_image")
+    o = orc.range_projection(g["points"], g["semantic"], g["rgb"], H=32, W=256)
+    for k in ("proj_range", "proj_semantic", "proj_mask", "proj_rgb", "proj_xyz", "proj_idx"):
+        np.testing.assert_array_equal(o[k], g[k], err_msg=k)
+    lr = orc.log_range(o["proj_range"])
+    np.testing.assert_array_equal(lr, g["log_range"])
+    np.testing.assert_allclose(orc.real_to_var(lr, size=2), g["var2"], rtol=1e-12, atol=0)
+    assert (g["proj_idx"] >= 0).sum() > 3000 and (g["proj_mask"] == 0).sum() > 0
+
+
+@pytest.mark.gpu
+def test_range_projection_gpu_bit_exact():
+    """nlr_range_project (HIP) against the reference's projection: every pixel picks the same (nearest) point."""
+    g = golden("fn_range_image")
+    dev = "cuda:0"
+    out = raydrop.range_projection(torch.from_numpy(g["points"]).to(dev), torch.from_numpy(g["semantic"]).to(dev),
+                                   torch.from_numpy(g["rgb"]).to(dev), H=32, W=256)
+    np.testing.assert_array_equal(out["proj_idx"].cpu().numpy(), g["proj_idx"])       # index work: bit-exact
+    np.testing.assert_array_equal(out["proj_mask"].cpu().numpy(), g["proj_mask"])
+    np.testing.assert_array_equal(out["proj_semantic"].cpu().numpy(), g["proj_semantic"])
+    np.testing.assert_array_equal(out["proj_range"].cpu().numpy(), g["proj_range"])   # f64 norm rounded to f32
+    np.testing.assert_array_equal(out["proj_rgb"].cpu().numpy(), g["proj_rgb"].astype(np.float32))
+    np.testing.assert_array_equal(out["proj_xyz"].cpu().numpy(), g["proj_xyz"])
+    f = raydrop.unet_features(out)
+    assert f.shape == (1, 6, 32, 256)
+    np.testing.assert_allclose(f[0, 0].cpu().numpy(), g["log_range"], atol=1e-6)
+    np.testing.assert_allclose(f[0, 5].cpu().numpy(), g["var2"], atol=1e-6)
+    # empty input and the mask quirk
+    e = raydrop.range_projection(torch.zeros(0, 3, dtype=torch.float64, device=dev), H=4, W=8)
+    assert (e["proj_idx"] == -1).all() and (e["proj_range"] == -1).all()
 
 
 @pytest.mark.gpu
