@@ -134,13 +134,31 @@ __device__ __forceinline__ void nlr_pad_chunk(Tape &tp) {  // one whole padding 
 // instead of serialising between layers (the kernel runs one wave per SIMD: nothing else would hide it).
 //   FPS = fragments per k-step (1; 2 for the hi/lo pairs of the split-bf16 path); PAR0 = parity of the first chunk
 //   init(ic<o>) -> f32x16 bias tile;  step(acc&, ic<g>, frag0, frag1);  epi(ic<o>, acc)
-template <int OT, int KG, int FPS, int PAR0, int IDX, class Init, class Step, class Epi>
-__device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, const Init &init, const Step &step, const Epi &epi) {
+// epilogue pieces of one finished tile, from piece P0 up to NP (exclusive)
+template <int O, int P0, int NP, class Epi>
+__device__ __forceinline__ void nlr_epi_rest(const Epi &epi, const f32x16 &acc) {
+    if constexpr (P0 < NP) {
+        epi(ic<O>{}, ic<P0>{}, acc);
+        nlr_epi_rest<O, P0 + 1, NP>(epi, acc);
+    }
+}
+template <int OT, int KG, int FPS, int NP, int PAR0, int IDX, class Init, class Step, class Epi>
+__device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, f32x16 &nxt, const Init &init, const Step &step,
+                                        const Epi &epi) {
+    // Schedule inside one output tile of KG k-steps (all compile time):
+    //   steps D .. D+NP-1 : one piece each of the PREVIOUS tile's epilogue (D = 3 lets that tile's last MFMA retire first)
+    //   step  IG          : bias rows of the NEXT tile are read from LDS, a few steps before its first MFMA needs them
+    constexpr int D = (KG >= NP + 3) ? 3 : 0;
+    constexpr int IG = (KG >= NP + D + 4) ? KG - 4 : KG - 1;
     if constexpr (IDX < OT * KG) {
         constexpr int o = IDX / KG, g = IDX % KG;
         if constexpr (g == 0) {
-            if constexpr (o > 0) prev = cur;
-            cur = init(ic<o>{});
+            if constexpr (o > 0) {
+                prev = cur;
+                cur = nxt;
+            } else {
+                cur = init(ic<0>{});
+            }
         }
         constexpr int P0 = (IDX * FPS) % NLR_CHUNK_FRAGS;
         constexpr int PAR = (PAR0 + (IDX * FPS) / NLR_CHUNK_FRAGS) & 1;
@@ -148,18 +166,26 @@ __device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, con
         uint4 f1 = f0;
         if constexpr (FPS == 2) f1 = tp.template step<P0 + 1, PAR>();
         step(cur, ic<g>{}, f0, f1);
-        if constexpr (g == 0 && o > 0) epi(ic<o - 1>{}, prev);
-        nlr_run<OT, KG, FPS, PAR0, IDX + 1>(tp, prev, cur, init, step, epi);
+        if constexpr (o > 0) {
+            if constexpr (g >= D && g - D < NP && g < KG - 1) epi(ic<o - 1>{}, ic<g - D>{}, prev);
+            if constexpr (g == KG - 1) nlr_epi_rest<o - 1, (KG - 1 - D < NP ? (KG - 1 - D > 0 ? KG - 1 - D : 0) : NP), NP>(epi, prev);
+        }
+        if constexpr (g == IG && o + 1 < OT) nxt = init(ic<o + 1>{});
+        // pin the issue order (fragment read-ahead, MFMA, epilogue piece): left alone, the scheduler sinks the
+        // ds_reads next to their use and every MFMA waits out the LDS latency
+        __builtin_amdgcn_sched_barrier(0);
+        nlr_run<OT, KG, FPS, NP, PAR0, IDX + 1>(tp, prev, cur, nxt, init, step, epi);
     } else {
-        epi(ic<OT - 1>{}, cur);
+        nlr_epi_rest<OT - 1, 0, NP>(epi, cur);
         nlr_pad<(OT * KG * FPS) % NLR_CHUNK_FRAGS, (PAR0 + nlr_nch(OT, KG, FPS) - 1) & 1>(tp);
     }
 }
 // EVEN: the GEMM is followed by one padding chunk when its chunk count is odd (keeps the parity of a runtime layer loop)
-template <int OT, int KG, int FPS, int PAR0, bool EVEN = false, class Init, class Step, class Epi>
+// NP: number of epilogue pieces per output tile
+template <int OT, int KG, int FPS, int NP, int PAR0, bool EVEN = false, class Init, class Step, class Epi>
 __device__ __forceinline__ void nlr_gemm(Tape &tp, const Init &init, const Step &step, const Epi &epi) {
-    f32x16 prev, cur;
-    nlr_run<OT, KG, FPS, PAR0, 0>(tp, prev, cur, init, step, epi);
+    f32x16 prev, cur, nxt;
+    nlr_run<OT, KG, FPS, NP, PAR0, 0>(tp, prev, cur, nxt, init, step, epi);
     if constexpr (EVEN && (nlr_nch(OT, KG, FPS) & 1)) nlr_pad_chunk<0, (PAR0 + nlr_nch(OT, KG, FPS)) & 1>(tp);
 }
 
@@ -191,6 +217,21 @@ __device__ __forceinline__ void nlr_pack1(TileH &dst, const f32x16 &src) {
         dst.f[s] = v;
     }
 }
+// piece P (0..7) of the pack: values 2P, 2P+1 -> one packed dword of the tile
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool RELU, int P>
+__device__ __forceinline__ void nlr_pack_piece(TileH &dst, const f32x16 &src) {
+    const f32x2 x = {src[2 * P], src[2 * P + 1]};
+    bf16x2 v = __builtin_convertvector(x, bf16x2);  // one v_cvt_pk_bf16_f32 (RNE)
+    if (RELU) {
+        const s16x2 z = {0, 0};  // max(bf16 bits as i16, 0): relu on the packed pair, -0 and negatives -> +0
+        v = __builtin_bit_cast(bf16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+    }
+    dst.f[P >> 2][2 * (P & 3)] = v[0];
+    dst.f[P >> 2][2 * (P & 3) + 1] = v[1];
+}
 // hi = bf16(x), lo = bf16(x - hi)   (x - hi is exact in f32)
 template <bool RELU>
 __device__ __forceinline__ void nlr_split1(TileH &hi, TileH &lo, const f32x16 &src) {
@@ -204,6 +245,18 @@ __device__ __forceinline__ void nlr_split1(TileH &hi, TileH &lo, const f32x16 &s
             hi.f[s][j] = hh;
             lo.f[s][j] = (__bf16)(v - (float)hh);
         }
+}
+template <bool RELU, int P>
+__device__ __forceinline__ void nlr_split_piece(TileH &hi, TileH &lo, const f32x16 &src) {
+    f32x2 x = {src[2 * P], src[2 * P + 1]};
+    if (RELU) x = __builtin_elementwise_max(x, (f32x2){0.0f, 0.0f});
+    const bf16x2 h = __builtin_convertvector(x, bf16x2);
+    const bf16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), bf16x2);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        hi.f[P >> 2][2 * (P & 3) + e] = h[e];
+        lo.f[P >> 2][2 * (P & 3) + e] = l[e];
+    }
 }
 template <bool RELU>
 __device__ __forceinline__ f32x16 nlr_act(const f32x16 &src) {
@@ -324,54 +377,54 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
 #pragma unroll
         for (int t = 0; t < FT; ++t) nlr_split1<false>(fh[t], fl[t], fin[t]);
         TileH dh[2], dl[2];
-        nlr_gemm<2, FK, 2, P_D0 & 1>(
+        nlr_gemm<2, FK, 2, 8, P_D0 & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D0, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
                 constexpr int G = decltype(g)::value;
                 nlr_mma_x3(a, f0, f1, fh[G >> 1].f[G & 1], fl[G >> 1].f[G & 1]);
             },
-            [&](auto o, const f32x16 &a) { nlr_split1<true>(dh[decltype(o)::value], dl[decltype(o)::value], a); });
+            [&](auto o, auto p, const f32x16 &a) { nlr_split_piece<true, decltype(p)::value>(dh[decltype(o)::value], dl[decltype(o)::value], a); });
         TileH hbl[BT];
-        nlr_gemm<BT, 4, 2, P_D2 & 1>(
+        nlr_gemm<BT, 4, 2, 8, P_D2 & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D2, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
                 constexpr int G = decltype(g)::value;
                 nlr_mma_x3(a, f0, f1, dh[G >> 1].f[G & 1], dl[G >> 1].f[G & 1]);
             },
-            [&](auto o, const f32x16 &a) {
-                constexpr int O = decltype(o)::value;
-                if constexpr (O == 0) raw_density = a[0];
-                nlr_split1<false>(hbe[O], hbl[O], a);
+            [&](auto o, auto p, const f32x16 &a) {
+                constexpr int O = decltype(o)::value, Pc = decltype(p)::value;
+                if constexpr (O == 0 && Pc == 0) raw_density = a[0];
+                nlr_split_piece<false, Pc>(hbe[O], hbl[O], a);
             });
         if constexpr (HT > 0) {
             TileH qh[HTA], ql[HTA];
-            nlr_gemm<HT, BT * 2, 2, P_H1 & 1>(
+            nlr_gemm<HT, BT * 2, 2, 8, P_H1 & 1>(
                 tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H1, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
                     constexpr int G = decltype(g)::value;
                     nlr_mma_x3(a, f0, f1, hbe[G >> 1].f[G & 1], hbl[G >> 1].f[G & 1]);
                 },
-                [&](auto o, const f32x16 &a) { nlr_split1<true>(qh[decltype(o)::value], ql[decltype(o)::value], a); });
-            nlr_gemm<1, HT * 2, 2, P_H2 & 1>(
+                [&](auto o, auto p, const f32x16 &a) { nlr_split_piece<true, decltype(p)::value>(qh[decltype(o)::value], ql[decltype(o)::value], a); });
+            nlr_gemm<1, HT * 2, 2, 1, P_H2 & 1>(
                 tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H2, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
                     constexpr int G = decltype(g)::value;
                     nlr_mma_x3(a, f0, f1, qh[G >> 1].f[G & 1], ql[G >> 1].f[G & 1]);
                 },
-                [&](auto, const f32x16 &a) { lo = a; });
+                [&](auto, auto, const f32x16 &a) { lo = a; });
         }
     } else {
         // ---- density trunk + heads on the exact-f32 MFMA
         f32x16 hid[2];
-        nlr_gemm<2, FG, 1, P_D0 & 1>(
+        nlr_gemm<2, FG, 1, 1, P_D0 & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D0, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, FT>(a, f0, fin); },
-            [&](auto o, const f32x16 &a) { hid[decltype(o)::value] = nlr_act<true>(a); });
+            [&](auto o, auto, const f32x16 &a) { hid[decltype(o)::value] = nlr_act<true>(a); });
         f32x16 hb[BT];
-        nlr_gemm<BT, 8, 1, P_D2 & 1>(
+        nlr_gemm<BT, 8, 1, 1, P_D2 & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D2, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, 2>(a, f0, hid); },
-            [&](auto o, const f32x16 &a) {
+            [&](auto o, auto, const f32x16 &a) {
                 constexpr int O = decltype(o)::value;
                 if constexpr (O == 0) raw_density = a[0];
                 hb[O] = a;
@@ -379,14 +432,14 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
             });
         if constexpr (HT > 0) {
             f32x16 hh[HTA];
-            nlr_gemm<HT, BT * 4, 1, P_H1 & 1>(
+            nlr_gemm<HT, BT * 4, 1, 1, P_H1 & 1>(
                 tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H1, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, BT>(a, f0, hb); },
-                [&](auto o, const f32x16 &a) { hh[decltype(o)::value] = nlr_act<true>(a); });
-            nlr_gemm<1, HT * 4, 1, P_H2 & 1>(
+                [&](auto o, auto, const f32x16 &a) { hh[decltype(o)::value] = nlr_act<true>(a); });
+            nlr_gemm<1, HT * 4, 1, 1, P_H2 & 1>(
                 tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H2, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, HTA>(a, f0, hh); },
-                [&](auto, const f32x16 &a) { lo = a; });
+                [&](auto, auto, const f32x16 &a) { lo = a; });
         }
     }
     if (h == 0 && valid) {
@@ -432,87 +485,87 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     if constexpr (!VIEW_F32) {
         nlr_pack1<false>(hbe[BT], encf);
         TileH x[WT], y[WT];
-        nlr_gemm<WT, (BT + 1) * 2, 1, P_V0 & 1>(
+        nlr_gemm<WT, (BT + 1) * 2, 1, 8, P_V0 & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V0, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                 constexpr int G = decltype(g)::value;
                 nlr_mma_bf16(a, f0, hbe[G >> 1].f[G & 1]);
             },
-            [&](auto o, const f32x16 &a) { nlr_pack1<true>(x[decltype(o)::value], a); });
-        nlr_gemm<WT, (WT + BT + 1) * 2, 1, P_V1 & 1>(
+            [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); });
+        nlr_gemm<WT, (WT + BT + 1) * 2, 1, 8, P_V1 & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V1, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                 constexpr int G = decltype(g)::value;
                 if constexpr (G < 2 * WT) nlr_mma_bf16(a, f0, x[G >> 1].f[G & 1]);
                 else nlr_mma_bf16(a, f0, hbe[(G - 2 * WT) >> 1].f[G & 1]);
             },
-            [&](auto o, const f32x16 &a) { nlr_pack1<true>(y[decltype(o)::value], a); });
+            [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(y[decltype(o)::value], a); });
         // hidden layers 2..D-1, two per iteration (y -> x -> y) so that no tile copies are needed
         uint32_t l = 2;
         for (; l + 1 < P.depth; l += 2) {
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm<WT, WT * 2, 1, P_VL & 1, true>(
+            nlr_gemm<WT, WT * 2, 1, 8, P_VL & 1, true>(
                 tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
                     nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
                 },
-                [&](auto o, const f32x16 &a) { nlr_pack1<true>(x[decltype(o)::value], a); });
-            nlr_gemm<WT, WT * 2, 1, P_VL & 1, true>(
+                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); });
+            nlr_gemm<WT, WT * 2, 1, 8, P_VL & 1, true>(
                 tp, [&](auto o) { return nlr_bias_tile(bl + WT * 32, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
                     nlr_mma_bf16(a, f0, x[G >> 1].f[G & 1]);
                 },
-                [&](auto o, const f32x16 &a) { nlr_pack1<true>(y[decltype(o)::value], a); });
+                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(y[decltype(o)::value], a); });
         }
         if (l < P.depth) {  // odd number of hidden layers: one more, result moved back into y
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm<WT, WT * 2, 1, P_VL & 1, true>(
+            nlr_gemm<WT, WT * 2, 1, 8, P_VL & 1, true>(
                 tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
                     nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
                 },
-                [&](auto o, const f32x16 &a) { nlr_pack1<true>(x[decltype(o)::value], a); });
+                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); });
 #pragma unroll
             for (int t = 0; t < WT; ++t) y[t] = x[t];
         }
-        nlr_gemm<1, WT * 2, 1, P_VL & 1>(
+        nlr_gemm<1, WT * 2, 1, 1, P_VL & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                 constexpr int G = decltype(g)::value;
                 nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
             },
-            [&](auto, const f32x16 &a) { out1 = a; });
+            [&](auto, auto, const f32x16 &a) { out1 = a; });
     } else {
         hbf[BT] = encf;
         f32x16 x[WT], y[WT];
-        nlr_gemm<WT, (BT + 1) * 4, 1, P_V0 & 1>(
+        nlr_gemm<WT, (BT + 1) * 4, 1, 1, P_V0 & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V0, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, BT + 1>(a, f0, hbf); },
-            [&](auto o, const f32x16 &a) { x[decltype(o)::value] = nlr_act<true>(a); });
-        nlr_gemm<WT, (WT + BT + 1) * 4, 1, P_V1 & 1>(
+            [&](auto o, auto, const f32x16 &a) { x[decltype(o)::value] = nlr_act<true>(a); });
+        nlr_gemm<WT, (WT + BT + 1) * 4, 1, 1, P_V1 & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V1, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                 constexpr int G = decltype(g)::value;
                 if constexpr (G < 4 * WT) nlr_mma_f32<G, WT>(a, f0, x);
                 else nlr_mma_f32<G - 4 * WT, BT + 1>(a, f0, hbf);
             },
-            [&](auto o, const f32x16 &a) { y[decltype(o)::value] = nlr_act<true>(a); });
+            [&](auto o, auto, const f32x16 &a) { y[decltype(o)::value] = nlr_act<true>(a); });
         for (uint32_t l = 2; l < P.depth; ++l) {
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm<WT, WT * 4, 1, P_VL & 1, true>(
+            nlr_gemm<WT, WT * 4, 1, 1, P_VL & 1, true>(
                 tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, WT>(a, f0, y); },
-                [&](auto o, const f32x16 &a) { x[decltype(o)::value] = nlr_act<true>(a); });
+                [&](auto o, auto, const f32x16 &a) { x[decltype(o)::value] = nlr_act<true>(a); });
 #pragma unroll
             for (int t = 0; t < WT; ++t) y[t] = x[t];
         }
-        nlr_gemm<1, WT * 4, 1, P_VL & 1>(
+        nlr_gemm<1, WT * 4, 1, 1, P_VL & 1>(
             tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, WT>(a, f0, y); },
-            [&](auto, const f32x16 &a) { out1 = a; });
+            [&](auto, auto, const f32x16 &a) { out1 = a; });
     }
     if (h == 0 && valid) {
 #pragma unroll
