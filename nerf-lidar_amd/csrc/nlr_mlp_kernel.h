@@ -30,70 +30,81 @@
 // row of accumulator register r for lane half h inside a 32-row tile
 __device__ __forceinline__ int nlr_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// ---- weight tape: global -> registers -> LDS (triple buffered), shared by the 4 waves of a workgroup -----------
+// ---- weight tape: global -> LDS by LDS-DMA (triple buffered), shared by the 4 waves of a workgroup ----------------
 // A chunk is 32 KiB = 32 fragments of 1 KiB (one fragment = the A operand of one MFMA for all 64 lanes).  Every
 // wave needs every fragment (each wave owns 32 samples and all output features), so staging through LDS cuts the
 // L2 -> CU weight traffic 4x against per-wave global loads and puts the fragment reads on ds_read_b128.
+// The refill is `global_load_lds_dwordx4` (one fragment = one wave-instruction, lane-linear in LDS, which is the
+// fragment layout): no VGPR staging and no ds_write pass.  Measured with in-kernel stamps, the
+// register-staged refill (8 global_load + 8 ds_write_b128 per wave per chunk) cost 38 % of the kernel: the
+// VGPR -> LDS store path moves ~79 B/clk/CU and does not overlap the fragment reads.
 // Schedule inside chunk c (f = fragment position, all positions are compile-time after unrolling):
-//   f = 20  the 256 threads write chunk c+1 (in registers since chunk c-2, f = 22) into LDS buffer (c+1)%3
-//   f = 21  __syncthreads(): chunk c+1 is visible to every wave
-//   f = 22  global loads of chunk c+3 are issued: two chunks (64 KiB per CU) are always in flight from L2, because
-//           one CU pulls only ~30 B/clk from L2 and a 32 KiB chunk is consumed every ~1000 cycles
+//   f = 8   s_waitcnt vmcnt(0) (this wave's quarter of chunk c+1, requested at (9, c-1), has landed) + s_barrier:
+//           chunk c+1 is complete and every wave has consumed its last fragment of chunk c-1
+//   f = 9   each wave requests its quarter (8 fragments) of chunk c+2 into LDS buffer (c+2)%3 = the buffer of c-1
 //   every f: the fragment f+8 is requested into an 8-deep register ring right after fragment f is consumed; from
 //            f = 24 on these requests run into chunk c+1, so no LDS latency is exposed at a chunk boundary.
-// Three buffers: the write at (20, c) lands in the buffer of chunk c-2, whose last read (31, c-2) lies before the
-// barrier (21, c-1) that every wave has passed; with two buffers it would race with slow waves still in chunk c-1.
+// A raw s_barrier without lgkmcnt(0) is enough: the last ds_read of chunk c-1 (issued at (23, c-1)) was waited for
+// by the MFMA that consumed it at (7, c), LDS reads return in order, and the DMA is tracked by vmcnt.
 #define NLR_CHUNK_FRAGS 32                       // fragments (1 KiB each) per chunk
 #define NLR_CHUNK_SLOTS (NLR_CHUNK_FRAGS * 64)   // uint4 slots per chunk
-#define NLR_CHUNK_LOADS (NLR_CHUNK_SLOTS / 256)  // 16-byte loads per thread per chunk
 #define NLR_NBUF 3
 #ifndef NLR_PF
 #define NLR_PF 8                                 // fragment read-ahead (register ring)
 #endif
+typedef const __attribute__((address_space(1))) void *nlr_gptr;
+typedef __attribute__((address_space(3))) void *nlr_lptr;
 struct Tape {
     const uint4 *__restrict__ base;
     uint4 *lds;  // [NLR_NBUF][NLR_CHUNK_SLOTS]
-    uint4 na[NLR_CHUNK_LOADS], nb[NLR_CHUNK_LOADS];  // two register sets: odd chunks travel in na, even in nb
     uint4 ring[NLR_PF];
     int cur, total, tid, lane;
     __device__ __forceinline__ uint4 *buf(int c) const { return lds + (c % NLR_NBUF) * NLR_CHUNK_SLOTS; }
-    __device__ __forceinline__ void load(uint4 (&r)[NLR_CHUNK_LOADS], int c) {
-        // wave-uniform chunk base (SALU) + one 32-bit per-lane byte offset: the loads take the
-        // `global_load_dwordx4 v, v_off, s[base:base+1]` form and need no per-load VALU address arithmetic
-        const char *cb = reinterpret_cast<const char *>(base) + (size_t)c * (NLR_CHUNK_SLOTS * 16);
-        const uint32_t voff = (uint32_t)tid * 16u;
-#pragma unroll
-        for (int i = 0; i < NLR_CHUNK_LOADS; ++i) r[i] = *reinterpret_cast<const uint4 *>(cb + i * 4096 + voff);
+    // this wave's quarter of chunk c: fragments 8w .. 8w+7, one LDS-DMA instruction each (LDS address = M0 + 16*lane).
+    // Inline asm on purpose: behind the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the next ds_read (it cannot
+    // tell the DMA's LDS target from the ring reads), which would expose the whole L2 latency once per chunk.  An asm
+    // DMA is invisible to hipcc's counters; `landed()` is the one wait that retires it.  M0 is saved and restored.
+    __device__ __forceinline__ void dma(int c) {
+        const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint64_t g = reinterpret_cast<uint64_t>(base) + (uint64_t)(uint32_t)c * (NLR_CHUNK_SLOTS * 16) + w * 8192u;
+        const uint32_t l = (uint32_t)(uintptr_t)(nlr_lptr)buf(c) + w * 8192u;
+        const uint32_t v = (uint32_t)lane * 16u;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %[k], m0\n\t"
+            "s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g0]\n\t"
+            "s_add_u32 m0, %[l], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g1]\n\t"
+            "s_add_u32 m0, %[l], 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g2]\n\t"
+            "s_add_u32 m0, %[l], 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g3]\n\t"
+            "s_add_u32 m0, %[l], 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g4]\n\t"
+            "s_add_u32 m0, %[l], 0x1400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g5]\n\t"
+            "s_add_u32 m0, %[l], 0x1800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g6]\n\t"
+            "s_add_u32 m0, %[l], 0x1c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g7]\n\t"
+            "s_mov_b32 m0, %[k]"
+            : [k] "=&s"(keep)
+            : [v] "v"(v), [l] "s"(l), [g0] "s"(g), [g1] "s"(g + 1024), [g2] "s"(g + 2048), [g3] "s"(g + 3072), [g4] "s"(g + 4096),
+              [g5] "s"(g + 5120), [g6] "s"(g + 6144), [g7] "s"(g + 7168)
+            : "memory", "scc");
     }
-    __device__ __forceinline__ void store(const uint4 (&r)[NLR_CHUNK_LOADS], int c) {
-        uint4 *q = buf(c) + tid;
-#pragma unroll
-        for (int i = 0; i < NLR_CHUNK_LOADS; ++i) q[i * 256] = r[i];
+    __device__ __forceinline__ void landed() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
     __device__ __forceinline__ void prologue() {
         cur = 0;
-        load(nb, 0);
-        store(nb, 0);
-        load(na, 1);  // the tape ends with 3 zero chunks of slack: no bounds checks anywhere in the stream
-        load(nb, 2);
-        __syncthreads();
+        dma(0);
+        dma(1);  // the tape ends with 3 zero chunks of slack: no bounds checks anywhere in the stream
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // both chunks and the bias block are visible to every wave
 #pragma unroll
         for (int f = 0; f < NLR_PF; ++f) ring[f] = buf(0)[f * 64 + lane];
     }
     // bookkeeping at fragment position F of the current chunk; returns the fragment (raw 16 bytes per lane).
-    // Two chunks are always in flight from L2: chunk c+1 (stored at F = 20 of chunk c) and chunk c+2; chunk c+3
-    // is requested at F = 22 into the register set chunk c+1 just left.
-    // PAR = parity of the current chunk index (a compile-time fact of the fixed GEMM sequence), so the register
-    // set is selected statically: chunks c+1 and c+3 have parity 1-PAR.
+    // PAR (parity of the chunk index) is unused by the DMA refill; kept so that the GEMM drivers stay unchanged.
     template <int F, int PAR>
     __device__ __forceinline__ uint4 step() {
-        if constexpr (F == 20) {
-            if constexpr (PAR == 0) store(na, cur + 1); else store(nb, cur + 1);
-        }
-        if constexpr (F == 21) __syncthreads();
-        if constexpr (F == 22) {
-            if constexpr (PAR == 0) load(na, cur + 3); else load(nb, cur + 3);
-        }
+        if constexpr (F == 8) landed();
+        if constexpr (F == 9) dma(cur + 2);
         const uint4 a = ring[F % NLR_PF];
         if constexpr (F + NLR_PF < NLR_CHUNK_FRAGS) ring[F % NLR_PF] = buf(cur)[(F + NLR_PF) * 64 + lane];
         else ring[F % NLR_PF] = buf(cur + 1)[(F + NLR_PF - NLR_CHUNK_FRAGS) * 64 + lane];
@@ -575,6 +586,8 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
             P.rgb[(size_t)c * P.M + sample] = sg * (1.0f + 2.0f * P.rgb_padding) - P.rgb_padding;
         }
     }
+    // the read-ahead DMA of the slack chunks must not outlive the workgroup's LDS allocation
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 
