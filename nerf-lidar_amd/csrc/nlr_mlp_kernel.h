@@ -39,16 +39,22 @@ __device__ __forceinline__ int nlr_row(int r, int h) { return (r & 3) + 8 * (r >
 // register-staged refill (8 global_load + 8 ds_write_b128 per wave per chunk) cost 38 % of the kernel: the
 // VGPR -> LDS store path moves ~79 B/clk/CU and does not overlap the fragment reads.
 // Schedule inside chunk c (f = fragment position, all positions are compile-time after unrolling):
-//   f = 8   s_waitcnt vmcnt(0) (this wave's quarter of chunk c+1, requested at (9, c-1), has landed) + s_barrier:
-//           chunk c+1 is complete and every wave has consumed its last fragment of chunk c-1
-//   f = 9   each wave requests its quarter (8 fragments) of chunk c+2 into LDS buffer (c+2)%3 = the buffer of c-1
+//   f = 8   s_waitcnt vmcnt(0) (this wave's quarter of chunk c+1, requested at (16, c-1), has landed); signal
+//   f = 16  once all four waves have signalled, each wave requests its quarter (8 fragments) of chunk c+2 into LDS
+//           buffer (c+2)%3 = the buffer of chunk c-1 (hand-shake: see Tape::signal)
 //   every f: the fragment f+8 is requested into an 8-deep register ring right after fragment f is consumed; from
 //            f = 24 on these requests run into chunk c+1, so no LDS latency is exposed at a chunk boundary.
-// A raw s_barrier without lgkmcnt(0) is enough: the last ds_read of chunk c-1 (issued at (23, c-1)) was waited for
-// by the MFMA that consumed it at (7, c), LDS reads return in order, and the DMA is tracked by vmcnt.
+// The last ds_read of chunk c-1 (issued at (23, c-1)) was waited for by the MFMA that consumed it at (7, c) and LDS
+// reads return in order, so at the signal every read of chunk c-1 by this wave is complete; the DMA is tracked by vmcnt.
 #define NLR_CHUNK_FRAGS 32                       // fragments (1 KiB each) per chunk
 #define NLR_CHUNK_SLOTS (NLR_CHUNK_FRAGS * 64)   // uint4 slots per chunk
 #define NLR_NBUF 3
+#ifndef NLR_SIG_F
+#define NLR_SIG_F 8
+#endif
+#ifndef NLR_POLL_F
+#define NLR_POLL_F 16
+#endif
 #ifndef NLR_PF
 #define NLR_PF 8                                 // fragment read-ahead (register ring)
 #endif
@@ -86,12 +92,55 @@ struct Tape {
               [g5] "s"(g + 5120), [g6] "s"(g + 6144), [g7] "s"(g + 7168)
             : "memory", "scc");
     }
-    __device__ __forceinline__ void landed() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    // Workgroup hand-shake without s_barrier.  A barrier per chunk cost 16 % of the kernel (stamps): the four
+    // waves drift by a few hundred cycles per chunk and a barrier makes every wave pay the maximum each time.  Instead:
+    //   (NLR_SIG_F, c)   own quarter of chunk c+1 has landed (vmcnt) and the last fragment of chunk c-1 is consumed
+    //                    -> lane 0 adds 1 to an LDS counter
+    //   (NLR_POLL_F-2, c) the counter is read; (NLR_POLL_F, c) spin until it shows 4 (c+1): every wave is past its signal of
+    //                    chunk c, so chunk c+1 is complete (read from f = 24 on) and the buffer of chunk c-1 is free -> DMA c+2
+    // Waves may now drift by NLR_POLL_F - NLR_SIG_F fragment steps before anyone waits.  LDS accesses of one CU are
+    // served in order by one unit, so counter and data need no fence beyond the vmcnt wait in front of the signal.
+    // All three steps are single asm statements: any C++ control flow here splits the unrolled MFMA chain into basic
+    // blocks and the ds_read / MFMA interleave is lost.  hipcc does not count asm LDS operations; its own counted
+    // lgkmcnt waits only get more conservative by that (the counter retires in order).
+    uint32_t *sig;
+    uint32_t sig_addr, seen;
+    __device__ __forceinline__ void signal() {
+        uint64_t sv;
+        asm volatile(
+            "s_waitcnt vmcnt(0)\n\t"
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b64 exec, 1\n\t"
+            "ds_add_u32 %[a], %[one]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [sv] "=&s"(sv)
+            : [a] "v"(sig_addr), [one] "v"(1u)
+            : "memory");
+    }
+    // The counter is read by an ordinary (volatile, LDS address space) load: hipcc tracks it and puts the exact counted
+    // lgkmcnt in front of await()'s asm, whatever it did with the ring reads in between (in padding steps they are dead
+    // code, so a hand-counted wait would be wrong there).  Only the rare re-poll inside the spin drains the counter.
+    __device__ __forceinline__ void peek() { seen = *reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t *>(sig_addr); }
+    __device__ __forceinline__ void await() {
+        const uint32_t target = 4u * (uint32_t)(cur + 1);
+        uint32_t t;
+        asm volatile(
+            "1:\n\t"
+            "v_readfirstlane_b32 %[t], %[seen]\n\t"
+            "s_cmp_ge_u32 %[t], %[target]\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_sleep 1\n\t"
+            "ds_read_b32 %[seen], %[a]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_branch 1b\n"
+            "2:"
+            : [seen] "+v"(seen), [t] "=&s"(t)
+            : [a] "v"(sig_addr), [target] "s"(target)
+            : "memory", "scc");
     }
     __device__ __forceinline__ void prologue() {
         cur = 0;
+        if (tid == 0) *sig = 0u;
         dma(0);
         dma(1);  // the tape ends with 3 zero chunks of slack: no bounds checks anywhere in the stream
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -103,8 +152,12 @@ struct Tape {
     // PAR (parity of the chunk index) is unused by the DMA refill; kept so that the GEMM drivers stay unchanged.
     template <int F, int PAR>
     __device__ __forceinline__ uint4 step() {
-        if constexpr (F == 8) landed();
-        if constexpr (F == 9) dma(cur + 2);
+        if constexpr (F == NLR_SIG_F) signal();
+        if constexpr (F == NLR_POLL_F - 2) peek();
+        if constexpr (F == NLR_POLL_F) {
+            await();
+            dma(cur + 2);
+        }
         const uint4 a = ring[F % NLR_PF];
         if constexpr (F + NLR_PF < NLR_CHUNK_FRAGS) ring[F % NLR_PF] = buf(cur)[(F + NLR_PF) * 64 + lane];
         else ring[F % NLR_PF] = buf(cur + 1)[(F + NLR_PF - NLR_CHUNK_FRAGS) * 64 + lane];
@@ -306,6 +359,7 @@ template <int WT, int BT, int FG, int HT, int PREC>
 __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     __shared__ __align__(16) uint4 lds_tape[NLR_NBUF * NLR_CHUNK_SLOTS];
     __shared__ __align__(16) float lds_bias[NLR_BIAS_MAX];
+    __shared__ uint32_t lds_sig;
     constexpr bool VIEW_F32 = (PREC == NLR_PREC_F32);
     constexpr bool X3 = (PREC == NLR_PREC_FAST);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -353,6 +407,8 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     Tape tp;
     tp.base = P.tape;
     tp.lds = lds_tape;
+    tp.sig = &lds_sig;
+    tp.sig_addr = (uint32_t)(uintptr_t)(nlr_lptr)&lds_sig;
     tp.total = (int)P.tape_chunks;
     tp.tid = threadIdx.x;
     tp.lane = lane;
@@ -488,7 +544,10 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 if (nlr_row(r, h) == (int)P.int_row) P.inten[sample] = lo[r];
         }
     }
-    if (P.rgb == nullptr) return;  // density/semantic/intensity only (uniform for the whole grid)
+    if (P.rgb == nullptr) {  // density/semantic/intensity only (uniform for the whole grid)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the LDS allocation
+        return;
+    }
 
     // ---- view MLP.  Layer 0 input = [bottleneck | enc]; layer 1 input = [x | bottleneck | enc] (skip concat,
     // models.py:1227-1228); the 27 dir-encoding features ride as one extra zero-padded 32-feature input tile.
