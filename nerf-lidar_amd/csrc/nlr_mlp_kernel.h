@@ -53,7 +53,7 @@ __device__ __forceinline__ int nlr_row(int r, int h) { return (r & 3) + 8 * (r >
 #define NLR_SIG_F 8
 #endif
 #ifndef NLR_POLL_F
-#define NLR_POLL_F 16
+#define NLR_POLL_F 22
 #endif
 #ifndef NLR_PF
 #define NLR_PF 8                                 // fragment read-ahead (register ring)
@@ -64,16 +64,21 @@ struct Tape {
     const uint4 *__restrict__ base;
     uint4 *lds;  // [NLR_NBUF][NLR_CHUNK_SLOTS]
     uint4 ring[NLR_PF];
-    int cur, total, tid, lane;
-    __device__ __forceinline__ uint4 *buf(int c) const { return lds + (c % NLR_NBUF) * NLR_CHUNK_SLOTS; }
+    // cur: chunks consumed so far by this workgroup (runs on across tiles); nxt: tape index of the next chunk to request
+    // (wraps at `total`, the chunks one tile consumes: a persistent workgroup streams the tape round and round);
+    // b0/b1/b2: LDS buffer (0..2) of chunks cur, cur+1, cur+2
+    int cur, nxt, total, tid, lane;
+    int b0, b1, b2;
+    __device__ __forceinline__ uint4 *buf(int b) const { return lds + b * NLR_CHUNK_SLOTS; }
     // this wave's quarter of chunk c: fragments 8w .. 8w+7, one LDS-DMA instruction each (LDS address = M0 + 16*lane).
     // Inline asm on purpose: behind the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the next ds_read (it cannot
     // tell the DMA's LDS target from the ring reads), which would expose the whole L2 latency once per chunk.  An asm
     // DMA is invisible to hipcc's counters; `landed()` is the one wait that retires it.  M0 is saved and restored.
-    __device__ __forceinline__ void dma(int c) {
+    __device__ __forceinline__ void dma(int b) {  // tape chunk `nxt` -> LDS buffer b
         const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const uint64_t g = reinterpret_cast<uint64_t>(base) + (uint64_t)(uint32_t)c * (NLR_CHUNK_SLOTS * 16) + w * 8192u;
-        const uint32_t l = (uint32_t)(uintptr_t)(nlr_lptr)buf(c) + w * 8192u;
+        const uint64_t g = reinterpret_cast<uint64_t>(base) + (uint64_t)(uint32_t)nxt * (NLR_CHUNK_SLOTS * 16) + w * 8192u;
+        const uint32_t l = (uint32_t)(uintptr_t)(nlr_lptr)buf(b) + w * 8192u;
+        nxt = (nxt + 1 == total) ? 0 : nxt + 1;
         const uint32_t v = (uint32_t)lane * 16u;
         uint32_t keep;
         asm volatile(
@@ -140,9 +145,11 @@ struct Tape {
     }
     __device__ __forceinline__ void prologue() {
         cur = 0;
+        nxt = 0;
+        b0 = 0, b1 = 1, b2 = 2;
         if (tid == 0) *sig = 0u;
         dma(0);
-        dma(1);  // the tape ends with 3 zero chunks of slack: no bounds checks anywhere in the stream
+        dma(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // both chunks and the bias block are visible to every wave
 #pragma unroll
@@ -156,12 +163,16 @@ struct Tape {
         if constexpr (F == NLR_POLL_F - 2) peek();
         if constexpr (F == NLR_POLL_F) {
             await();
-            dma(cur + 2);
+            dma(b2);
         }
         const uint4 a = ring[F % NLR_PF];
-        if constexpr (F + NLR_PF < NLR_CHUNK_FRAGS) ring[F % NLR_PF] = buf(cur)[(F + NLR_PF) * 64 + lane];
-        else ring[F % NLR_PF] = buf(cur + 1)[(F + NLR_PF - NLR_CHUNK_FRAGS) * 64 + lane];
-        if constexpr (F == NLR_CHUNK_FRAGS - 1) ++cur;
+        if constexpr (F + NLR_PF < NLR_CHUNK_FRAGS) ring[F % NLR_PF] = buf(b0)[(F + NLR_PF) * 64 + lane];
+        else ring[F % NLR_PF] = buf(b1)[(F + NLR_PF - NLR_CHUNK_FRAGS) * 64 + lane];
+        if constexpr (F == NLR_CHUNK_FRAGS - 1) {
+            ++cur;
+            const int t = b0;
+            b0 = b1, b1 = b2, b2 = t;
+        }
         return a;
     }
 };
@@ -364,10 +375,6 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     constexpr bool X3 = (PREC == NLR_PREC_FAST);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const uint32_t sample = (blockIdx.x * 4 + wave) * 32 + col;
-    const bool valid = sample < P.M;
-    const uint32_t sc = valid ? sample : P.M - 1;
-    const uint32_t ray = sc / P.S;
     constexpr int FT = (FG + 3) / 4;
     constexpr int HTA = HT > 0 ? HT : 1;
     // bias block offsets (floats)
@@ -386,10 +393,14 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     constexpr int P_V1 = P_V0 + nlr_nch(WT, (BT + 1) * KV, 1);
     constexpr int P_VL = P_V1 + nlr_nch(WT, (WT + BT + 1) * KV, 1);  // layers >= 2 occupy an even number of chunks each
 
-    // ---- everything that comes from global memory besides the weight tape is requested up front: the kernel runs
-    // one wave per SIMD, so a load in the middle of the chain would be pure exposed latency.
-    f32x4 fv[FG];
-    {
+    // ---- persistent workgroup: one per CU, tiles (4 waves x 32 samples) taken round-robin.  The bias block is staged
+    // once, the weight tape streams round and round (its read-ahead runs across the tile seam into chunk 0 of the next
+    // tile), and the next tile's inputs are requested as soon as this tile's are unpacked: no prologue, dispatch gap or
+    // exposed load latency between tiles.
+    const uint32_t ntiles = (P.M + 127) / 128;
+    auto load_inputs = [&](uint32_t tile, f32x4 (&fv)[FG], f32x4 (&ev)[4]) {
+        const uint32_t smp = (tile * 4 + wave) * 32 + col;
+        const uint32_t sc = smp < P.M ? smp : P.M - 1;
         const float *fp = P.feat + (size_t)sc * P.F;
 #pragma unroll
         for (int g = 0; g < FG; ++g) {
@@ -397,10 +408,12 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
             fv[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (f0 + 4 <= P.F) fv[g] = *reinterpret_cast<const f32x4 *>(fp + f0);
         }
-    }
-    f32x4 ev[4];
+        const uint32_t ray = sc / P.S;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ev[q] = *reinterpret_cast<const f32x4 *>(P.enc + (size_t)ray * 32 + 8 * q + 4 * h);
+        for (int q = 0; q < 4; ++q) ev[q] = *reinterpret_cast<const f32x4 *>(P.enc + (size_t)ray * 32 + 8 * q + 4 * h);
+    };
+    f32x4 fv[FG], ev[4];
+    load_inputs(blockIdx.x, fv, ev);
     for (uint32_t i = threadIdx.x * 4; i < P.bias_count; i += 1024)
         *reinterpret_cast<f32x4 *>(lds_bias + i) = *reinterpret_cast<const f32x4 *>(P.bias_all + i);
 
@@ -409,11 +422,14 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     tp.lds = lds_tape;
     tp.sig = &lds_sig;
     tp.sig_addr = (uint32_t)(uintptr_t)(nlr_lptr)&lds_sig;
-    tp.total = (int)P.tape_chunks;
+    tp.total = P.rgb ? (int)P.tape_chunks : P_V0;  // without the view MLP a tile consumes the trunk + head chunks only
     tp.tid = threadIdx.x;
     tp.lane = lane;
     tp.prologue();  // ends with __syncthreads(): the bias block is visible too
 
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t sample = (tile * 4 + wave) * 32 + col;
+    const bool valid = sample < P.M;
     // ---- features / direction encoding -> accumulator-layout tiles (lane half h holds rows 8q+4h..+3 of each group)
     f32x16 fin[FT];
 #pragma unroll
@@ -429,6 +445,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) encf[q * 4 + e] = ev[q][e];
+    if (tile + gridDim.x < ntiles) load_inputs(tile + gridDim.x, fv, ev);
 
     float raw_density = 0.0f;
     f32x16 lo;  // [K logits | intensity] output tile of the heads
@@ -544,10 +561,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 if (nlr_row(r, h) == (int)P.int_row) P.inten[sample] = lo[r];
         }
     }
-    if (P.rgb == nullptr) {  // density/semantic/intensity only (uniform for the whole grid)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the LDS allocation
-        return;
-    }
+    if (P.rgb == nullptr) continue;  // density/semantic/intensity only (uniform for the whole grid)
 
     // ---- view MLP.  Layer 0 input = [bottleneck | enc]; layer 1 input = [x | bottleneck | enc] (skip concat,
     // models.py:1227-1228); the 27 dir-encoding features ride as one extra zero-padded 32-feature input tile.
@@ -645,7 +659,8 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
             P.rgb[(size_t)c * P.M + sample] = sg * (1.0f + 2.0f * P.rgb_padding) - P.rgb_padding;
         }
     }
-    // the read-ahead DMA of the slack chunks must not outlive the workgroup's LDS allocation
+    }  // tile loop
+    // the read-ahead DMA must not outlive the workgroup's LDS allocation
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

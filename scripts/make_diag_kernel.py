@@ -5,8 +5,7 @@ writes OUT_DIR/diag_kernel.h + OUT_DIR/diag_inst.hip.  Build one instance per ab
 and link it in place of build/nlr_mlp_inst_8_4_2.o (scripts/diag_build.sh); scripts/stamp_probe.py reads the stamps.
   s_memtime stamps at the phase boundaries of the FAST (bf16 view MLP) path go behind the intensity buffer.
   NLR_DIAG bits: 1 no tape refill (DMA), 2 epilogue reduced to register moves, 4 no fragment ring reads,
-                 8 no per-chunk wait+barrier,
-                 16 no per-chunk vmcnt wait (barrier kept), 32 no per-chunk barrier (wait kept).   Masked builds compute garbage: timing only.
+                 8 no per-chunk hand-shake (signal/peek/await).   Masked builds compute garbage: timing only.
 """
 import os
 import sys
@@ -23,8 +22,8 @@ def sub(s, old, new, count=1):
 s = src
 s = sub(s, '#include "nlr_kernels.h"', '#include "%s/nerf-lidar_amd/csrc/nlr_kernels.h"\n#ifndef NLR_DIAG\n#define NLR_DIAG 0\n#endif' % ROOT)
 # ablation bits
-s = sub(s, "        if constexpr (F == 8) landed();\n        if constexpr (F == 9) dma(cur + 2);",
-        "#if !(NLR_DIAG & 8)\n        if constexpr (F == 8) landed();\n#endif\n#if !(NLR_DIAG & 1)\n        if constexpr (F == 9) dma(cur + 2);\n#endif")
+s = sub(s, "        if constexpr (F == NLR_SIG_F) signal();\n        if constexpr (F == NLR_POLL_F - 2) peek();\n        if constexpr (F == NLR_POLL_F) {\n            await();\n            dma(cur + 2);\n        }",
+        "#if !(NLR_DIAG & 8)\n        if constexpr (F == NLR_SIG_F) signal();\n        if constexpr (F == NLR_POLL_F - 2) peek();\n        if constexpr (F == NLR_POLL_F) await();\n#endif\n#if !(NLR_DIAG & 1)\n        if constexpr (F == NLR_POLL_F) dma(cur + 2);\n#endif")
 s = sub(s, "        if constexpr (F + NLR_PF < NLR_CHUNK_FRAGS) ring[F % NLR_PF] = buf(cur)[(F + NLR_PF) * 64 + lane];\n"
            "        else ring[F % NLR_PF] = buf(cur + 1)[(F + NLR_PF - NLR_CHUNK_FRAGS) * 64 + lane];",
         "#if !(NLR_DIAG & 4)\n        if constexpr (F + NLR_PF < NLR_CHUNK_FRAGS) ring[F % NLR_PF] = buf(cur)[(F + NLR_PF) * 64 + lane];\n"
@@ -33,8 +32,6 @@ s = sub(s, "    const f32x2 x = {src[2 * P], src[2 * P + 1]};\n    bf16x2 v = __
         "#if NLR_DIAG & 2\n    dst.f[P >> 2][2 * (P & 3)] = __builtin_bit_cast(bf16x2, src[2 * P])[1];\n"
         "    dst.f[P >> 2][2 * (P & 3) + 1] = __builtin_bit_cast(bf16x2, src[2 * P])[0];\n    return;\n#endif\n"
         "    const f32x2 x = {src[2 * P], src[2 * P + 1]};\n    bf16x2 v = __builtin_convertvector(x, bf16x2);")
-s = sub(s, '        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __builtin_amdgcn_s_barrier();',
-        '#if !(NLR_DIAG & 16)\n        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n#endif\n#if !(NLR_DIAG & 32)\n        __builtin_amdgcn_s_barrier();\n#endif')
 # stamps
 s = sub(s, "    Tape tp;\n",
         "    unsigned long long stamps[12]; int ns = 0;\n"
