@@ -217,14 +217,20 @@ __device__ __forceinline__ void nlr_epi_rest(const Epi &epi, const f32x16 &acc) 
         nlr_epi_rest<O, P0 + 1, NP>(epi, acc);
     }
 }
-template <int OT, int KG, int FPS, int NP, int PAR0, int IDX, class Init, class Step, class Epi>
-__device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, f32x16 &nxt, const Init &init, const Step &step,
-                                        const Epi &epi) {
+// NPP > 0: `pend(ic<p>)`, p < NPP, are the epilogue pieces of the PREVIOUS GEMM's last output tile; they run in the
+//          MFMA shadow of this GEMM's first output tile (whose first k-steps must not read that tile: true for the
+//          view layers, where k-step g reads input tile g/2 and the pending tile is the last one).
+// DEFER:   the last output tile of this GEMM is handed back raw in `last` (its epilogue becomes the next GEMM's `pend`)
+//          instead of being post-processed serially behind the last MFMA, where nothing would hide it.
+template <int OT, int KG, int FPS, int NP, int NPP, bool DEFER, int PAR0, int IDX, class Init, class Step, class Epi, class Pend>
+__device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, f32x16 &nxt, f32x16 &last, const Init &init,
+                                        const Step &step, const Epi &epi, const Pend &pend) {
     // Schedule inside one output tile of KG k-steps (all compile time):
     //   steps D .. D+NP-1 : one piece each of the PREVIOUS tile's epilogue (D = 3 lets that tile's last MFMA retire first)
     //   step  IG          : bias rows of the NEXT tile are read from LDS, a few steps before its first MFMA needs them
     constexpr int D = (KG >= NP + 3) ? 3 : 0;
     constexpr int IG = (KG >= NP + D + 4) ? KG - 4 : KG - 1;
+    static_assert(NPP == 0 || KG >= NPP + 3, "pending epilogue needs a long enough first tile");
     if constexpr (IDX < OT * KG) {
         constexpr int o = IDX / KG, g = IDX % KG;
         if constexpr (g == 0) {
@@ -244,14 +250,17 @@ __device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, f32
         if constexpr (o > 0) {
             if constexpr (g >= D && g - D < NP && g < KG - 1) epi(ic<o - 1>{}, ic<g - D>{}, prev);
             if constexpr (g == KG - 1) nlr_epi_rest<o - 1, (KG - 1 - D < NP ? (KG - 1 - D > 0 ? KG - 1 - D : 0) : NP), NP>(epi, prev);
+        } else if constexpr (NPP > 0) {
+            if constexpr (g >= 3 && g - 3 < NPP) pend(ic<g - 3>{});
         }
         if constexpr (g == IG && o + 1 < OT) nxt = init(ic<o + 1>{});
         // pin the issue order (fragment read-ahead, MFMA, epilogue piece): left alone, the scheduler sinks the
         // ds_reads next to their use and every MFMA waits out the LDS latency
         __builtin_amdgcn_sched_barrier(0);
-        nlr_run<OT, KG, FPS, NP, PAR0, IDX + 1>(tp, prev, cur, nxt, init, step, epi);
+        nlr_run<OT, KG, FPS, NP, NPP, DEFER, PAR0, IDX + 1>(tp, prev, cur, nxt, last, init, step, epi, pend);
     } else {
-        nlr_epi_rest<OT - 1, 0, NP>(epi, cur);
+        if constexpr (DEFER) last = cur;
+        else nlr_epi_rest<OT - 1, 0, NP>(epi, cur);
         nlr_pad<(OT * KG * FPS) % NLR_CHUNK_FRAGS, (PAR0 + nlr_nch(OT, KG, FPS) - 1) & 1>(tp);
     }
 }
@@ -259,9 +268,16 @@ __device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, f32
 // NP: number of epilogue pieces per output tile
 template <int OT, int KG, int FPS, int NP, int PAR0, bool EVEN = false, class Init, class Step, class Epi>
 __device__ __forceinline__ void nlr_gemm(Tape &tp, const Init &init, const Step &step, const Epi &epi) {
-    f32x16 prev, cur, nxt;
-    nlr_run<OT, KG, FPS, NP, PAR0, 0>(tp, prev, cur, nxt, init, step, epi);
+    f32x16 prev, cur, nxt, last;
+    nlr_run<OT, KG, FPS, NP, 0, false, PAR0, 0>(tp, prev, cur, nxt, last, init, step, epi, [](auto) {});
     if constexpr (EVEN && (nlr_nch(OT, KG, FPS) & 1)) nlr_pad_chunk<0, (PAR0 + nlr_nch(OT, KG, FPS)) & 1>(tp);
+}
+// software-pipelined across GEMMs (see nlr_run): pend = previous GEMM's deferred tile, last = this GEMM's
+template <int OT, int KG, int NP, int NPP, bool DEFER, int PAR0, bool EVEN = false, class Init, class Step, class Epi, class Pend>
+__device__ __forceinline__ void nlr_gemm_pipe(Tape &tp, f32x16 &last, const Init &init, const Step &step, const Epi &epi, const Pend &pend) {
+    f32x16 prev, cur, nxt;
+    nlr_run<OT, KG, 1, NP, NPP, DEFER, PAR0, 0>(tp, prev, cur, nxt, last, init, step, epi, pend);
+    if constexpr (EVEN && (nlr_nch(OT, KG, 1) & 1)) nlr_pad_chunk<0, (PAR0 + nlr_nch(OT, KG, 1)) & 1>(tp);
 }
 
 __device__ __forceinline__ f32x16 nlr_bias_tile(const float *bias, int o, int h) {
@@ -534,26 +550,24 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     // Per-sample heads are stored class-major ([K, M], [3, M]): one store instruction writes two 128-byte runs.
     if constexpr (HT > 0) {
         if (P.K > 0) {  // softmax over rows [0,K) of this column, split over the two lane halves
-            float mx = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (nlr_row(r, h) < (int)P.K) mx = fmaxf(mx, lo[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float e[16], s = 0.0f;
+            // Branch-free: rows >= K take -inf (exp -> 0), so the only exec-masked instructions are the stores; a
+            // per-row `if (row < K)` differs between the lane halves and costs an exec save/restore per row.
+            float e[16], mx = -INFINITY, s = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                e[r] = 0.0f;
-                if (nlr_row(r, h) < (int)P.K) {
-                    e[r] = expf(lo[r] - mx);
-                    s += e[r];
-                }
+                e[r] = nlr_row(r, h) < (int)P.K ? lo[r] : -INFINITY;
+                mx = fmaxf(mx, e[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                e[r] = expf(e[r] - mx);
+                s += e[r];
             }
             s += __shfl_xor(s, 32, 64);
-            if (valid) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (nlr_row(r, h) < (int)P.K) P.sem[(size_t)nlr_row(r, h) * P.M + sample] = e[r] / s;
-            }
+            for (int r = 0; r < 16; ++r)
+                if (valid && nlr_row(r, h) < (int)P.K) P.sem[(size_t)nlr_row(r, h) * P.M + sample] = e[r] / s;
         }
         if (P.inten && valid) {
 #pragma unroll
@@ -569,59 +583,79 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     if constexpr (!VIEW_F32) {
         nlr_pack1<false>(hbe[BT], encf);
         TileH x[WT], y[WT];
-        nlr_gemm<WT, (BT + 1) * 2, 1, 8, P_V0 & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V0, o.value, h); },
+        // The last output tile of every layer is carried raw (`cx` / `cy`) and packed in the MFMA shadow of the next
+        // layer's first tile: x/y[WT-1] is read last there (k-steps 2 WT - 2, 2 WT - 1), so nothing waits for it.
+        f32x16 cx, cy;
+        nlr_gemm_pipe<WT, (BT + 1) * 2, 8, 0, true, P_V0 & 1>(
+            tp, cx, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V0, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                 constexpr int G = decltype(g)::value;
                 nlr_mma_bf16(a, f0, hbe[G >> 1].f[G & 1]);
             },
-            [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); });
-        nlr_gemm<WT, (WT + BT + 1) * 2, 1, 8, P_V1 & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V1, o.value, h); },
+            [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); }, [](auto) {});
+        nlr_gemm_pipe<WT, (WT + BT + 1) * 2, 8, 8, true, P_V1 & 1>(
+            tp, cy, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V1, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                 constexpr int G = decltype(g)::value;
                 if constexpr (G < 2 * WT) nlr_mma_bf16(a, f0, x[G >> 1].f[G & 1]);
                 else nlr_mma_bf16(a, f0, hbe[(G - 2 * WT) >> 1].f[G & 1]);
             },
-            [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(y[decltype(o)::value], a); });
+            [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(y[decltype(o)::value], a); },
+            [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(x[WT - 1], cx); });
         // hidden layers 2..D-1, two per iteration (y -> x -> y) so that no tile copies are needed
         uint32_t l = 2;
         for (; l + 1 < P.depth; l += 2) {
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm<WT, WT * 2, 1, 8, P_VL & 1, true>(
-                tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
+            nlr_gemm_pipe<WT, WT * 2, 8, 8, true, P_VL & 1, true>(
+                tp, cx, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
                     nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
                 },
-                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); });
-            nlr_gemm<WT, WT * 2, 1, 8, P_VL & 1, true>(
-                tp, [&](auto o) { return nlr_bias_tile(bl + WT * 32, o.value, h); },
+                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); },
+                [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(y[WT - 1], cy); });
+            nlr_gemm_pipe<WT, WT * 2, 8, 8, true, P_VL & 1, true>(
+                tp, cy, [&](auto o) { return nlr_bias_tile(bl + WT * 32, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
                     nlr_mma_bf16(a, f0, x[G >> 1].f[G & 1]);
                 },
-                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(y[decltype(o)::value], a); });
+                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(y[decltype(o)::value], a); },
+                [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(x[WT - 1], cx); });
         }
         if (l < P.depth) {  // odd number of hidden layers: one more, result moved back into y
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm<WT, WT * 2, 1, 8, P_VL & 1, true>(
-                tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
+            nlr_gemm_pipe<WT, WT * 2, 8, 8, false, P_VL & 1, true>(
+                tp, cx, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
                     nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
                 },
-                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); });
+                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); },
+                [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(y[WT - 1], cy); });
 #pragma unroll
             for (int t = 0; t < WT; ++t) y[t] = x[t];
+            cy = cx;  // not pending any more: y[WT-1] is complete (the flag below is compile-time, see `odd`)
         }
-        nlr_gemm<1, WT * 2, 1, 1, P_VL & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
-                constexpr int G = decltype(g)::value;
-                nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
-            },
-            [&](auto, auto, const f32x16 &a) { out1 = a; });
+        const bool odd = ((P.depth - 2) & 1) != 0;
+        if (odd) {
+            nlr_gemm_pipe<1, WT * 2, 1, 0, false, P_VL & 1>(
+                tp, cx, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
+                    constexpr int G = decltype(g)::value;
+                    nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
+                },
+                [&](auto, auto, const f32x16 &a) { out1 = a; }, [](auto) {});
+        } else {
+            nlr_gemm_pipe<1, WT * 2, 1, 8, false, P_VL & 1>(
+                tp, cx, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
+                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
+                    constexpr int G = decltype(g)::value;
+                    nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
+                },
+                [&](auto, auto, const f32x16 &a) { out1 = a; },
+                [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(y[WT - 1], cy); });
+        }
     } else {
         hbf[BT] = encf;
         f32x16 x[WT], y[WT];

@@ -22,7 +22,7 @@ off += al(N * S * 40 * 4) + al(N * 32 * 4) + al(N * S * 3 * 4) + al(N * S * 19 *
 inten_off = off
 for _ in range(3): m.render_rays(batch)
 torch.cuda.synchronize()
-raw = m._ws[inten_off + N * S * 4: inten_off + N * S * 4 + 4096 * 128].cpu().numpy().view(np.uint64).reshape(4096, 16)
+raw = m._ws[inten_off + N * S * 4: inten_off + N * S * 4 + 256 * 128].cpu().numpy().view(np.uint64).reshape(256, 16)  # one row per persistent workgroup (its last tile)
 d = np.diff(raw[:, :7].astype(np.int64), axis=1)
 clk = (raw[:, 7].astype(np.int64) - raw[:, 0].astype(np.int64)) / np.maximum(raw[:, 9].astype(np.int64) - raw[:, 8].astype(np.int64), 1) * 100.0
 print("in-kernel clock (MHz, median over blocks):", np.median(clk))
