@@ -585,15 +585,18 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         TileH x[WT], y[WT];
         // The last output tile of every layer is carried raw (`cx` / `cy`) and packed in the MFMA shadow of the next
         // layer's first tile: x/y[WT-1] is read last there (k-steps 2 WT - 2, 2 WT - 1), so nothing waits for it.
+        // Needs 2 WT - 2 > 6 k-steps ahead of the first read of that tile: WT >= 6; narrower layers run the serial form.
+        constexpr bool PIPE = WT >= 6;
+        constexpr int NPP = PIPE ? 8 : 0;
         f32x16 cx, cy;
-        nlr_gemm_pipe<WT, (BT + 1) * 2, 8, 0, true, P_V0 & 1>(
+        nlr_gemm_pipe<WT, (BT + 1) * 2, 8, 0, PIPE, P_V0 & 1>(
             tp, cx, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V0, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                 constexpr int G = decltype(g)::value;
                 nlr_mma_bf16(a, f0, hbe[G >> 1].f[G & 1]);
             },
             [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); }, [](auto) {});
-        nlr_gemm_pipe<WT, (WT + BT + 1) * 2, 8, 8, true, P_V1 & 1>(
+        nlr_gemm_pipe<WT, (WT + BT + 1) * 2, 8, NPP, PIPE, P_V1 & 1>(
             tp, cy, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V1, o.value, h); },
             [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                 constexpr int G = decltype(g)::value;
@@ -606,7 +609,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         uint32_t l = 2;
         for (; l + 1 < P.depth; l += 2) {
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm_pipe<WT, WT * 2, 8, 8, true, P_VL & 1, true>(
+            nlr_gemm_pipe<WT, WT * 2, 8, NPP, PIPE, P_VL & 1, true>(
                 tp, cx, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
@@ -614,7 +617,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 },
                 [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); },
                 [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(y[WT - 1], cy); });
-            nlr_gemm_pipe<WT, WT * 2, 8, 8, true, P_VL & 1, true>(
+            nlr_gemm_pipe<WT, WT * 2, 8, NPP, PIPE, P_VL & 1, true>(
                 tp, cy, [&](auto o) { return nlr_bias_tile(bl + WT * 32, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
@@ -625,7 +628,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         }
         if (l < P.depth) {  // odd number of hidden layers: one more, result moved back into y
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm_pipe<WT, WT * 2, 8, 8, false, P_VL & 1, true>(
+            nlr_gemm_pipe<WT, WT * 2, 8, NPP, false, P_VL & 1, true>(
                 tp, cx, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
@@ -647,7 +650,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 },
                 [&](auto, auto, const f32x16 &a) { out1 = a; }, [](auto) {});
         } else {
-            nlr_gemm_pipe<1, WT * 2, 1, 8, false, P_VL & 1>(
+            nlr_gemm_pipe<1, WT * 2, 1, NPP, false, P_VL & 1>(
                 tp, cx, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
