@@ -97,14 +97,6 @@ __device__ __forceinline__ void nlr_corner_idx(const GridParams &gp, uint32_t le
     }
 }
 
-// The dispatcher deals workgroups round-robin over the 8 XCDs (each with its own 4 MiB L2).  This remap hands every
-// XCD a contiguous span of logical blocks instead, so that neighbouring rays (which gather the same hash-grid cells)
-// share one L2 rather than pulling the same lines into eight.  Blocks past the last multiple of 8 keep their index.
-__device__ __forceinline__ uint32_t nlr_xcd_block(uint32_t b, uint32_t nb) {
-    const uint32_t per = nb >> 3;
-    if (b >= per * 8u) return b;
-    return (b & 7u) * per + (b >> 3);
-}
 __device__ __forceinline__ float nlr_wave_incl_scan_add(float v, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {

@@ -232,7 +232,7 @@ __device__ __forceinline__ float nlr_group8_sum(float v) {
 
 template <typename T, int C>
 __global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat) {
-    const uint32_t gt = nlr_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = cp.N * cp.S;
     uint32_t m = gt >> 3;
     const uint32_t j = gt & 7;
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParam
         sw[64 * mp.F + 64 + threadIdx.x] = mp.w2[threadIdx.x];
     }
     __syncthreads();
-    const uint32_t gt = nlr_xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = cp.N * cp.S;
     uint32_t m = gt >> 3;
     const uint32_t j = gt & 7;
