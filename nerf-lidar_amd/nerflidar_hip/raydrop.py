@@ -200,3 +200,39 @@ def unet_features(proj, var=True):
         win = torch.stack([torch.roll(lr, i, dims=1) for i in range(-2, 2)], dim=-1)
         feats.append(win.var(dim=-1, unbiased=False))
     return torch.stack(feats, 0)[None]
+
+
+# ---- applying a trained ray-drop UNet to a rendered sweep (scope row f-4, second half) ----------------------------------
+def apply_ray_drop(proj, logits, mask_thre=0.5, place_car=False, car_label=13, sky_label=10, road_label=0, road_z=-3.0):
+    """NeRF_Lidar_code/src/drop_simulation_rays.py:88-166, the `save_near` branch without depth filter: keep the range-image
+    pixels whose keep-probability `softmax(logits)[1]` exceeds `mask_thre` and that hold a point; with `place_car`, car
+    pixels are first thresholded at their own median probability (:103-108).  Then drop sky points and road points below
+    z = -3 m (:158-164).  proj: dict from `range_projection`; logits [2,H,W] (or [1,2,H,W]).  Returns (points [K,3] f32,
+    labels [K] int64), both CUDA tensors, in row-major pixel order like the reference's boolean indexing."""
+    logits = logits.reshape((2,) + tuple(proj["proj_range"].shape)).float()
+    prob = torch.softmax(logits, dim=0)[1]
+    sem = proj["proj_semantic"]
+    if place_car:
+        car = sem == car_label
+        if bool(car.any()):
+            thre = torch.quantile(prob[car], 0.5)  # np.percentile(., 50): linear interpolation, the torch default too
+            prob = torch.where(car, (prob > thre).to(prob.dtype), prob)
+    keep = (prob > mask_thre) & (proj["proj_mask"] == 1)
+    pts, lab = proj["proj_xyz"][keep], sem[keep].to(torch.int64)
+    ok = lab != sky_label
+    pts, lab = pts[ok], lab[ok]
+    ok = ~((lab == road_label) & (pts[:, 2] < road_z))
+    return pts[ok], lab[ok]
+
+
+def write_points_and_labels(index, savepath, points, labels):
+    """KITTI-style pair as drop_simulation_rays.py:14-22 writes it: `velodyne/%06d.bin` = the points' float32 values back to
+    back (three per point here), `labels/%06d.label` = uint32 per point."""
+    import os
+    import numpy as np
+    os.makedirs(os.path.join(savepath, "velodyne"), exist_ok=True)
+    os.makedirs(os.path.join(savepath, "labels"), exist_ok=True)
+    p = points.detach().cpu().numpy() if isinstance(points, torch.Tensor) else np.asarray(points)
+    l = labels.detach().cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
+    p.astype(np.float32).tofile(os.path.join(savepath, "velodyne", "{:06d}.bin".format(index)))
+    l.astype(np.uint32).tofile(os.path.join(savepath, "labels", "{:06d}.label".format(index)))

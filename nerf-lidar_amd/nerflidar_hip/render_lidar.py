@@ -1,0 +1,133 @@
+"""`render_lidar`-equivalent driver (SURVEY 8b "who calls it"): sweeps -> fused render -> the files the reference writes.
+
+Restates Z/render_lidar.py:106-162 around `nerflidar_hip.models.render_image`: per sweep, render the LiDAR ray batch with
+`image=False`, then `points = (origins + depth * directions) / scale_factor`, `labels = argmax(semantic)` and save
+`points_%04d.npy`, `points_semantic_%04d.npy`, `points_rgb_%04d.npy` under `<render_dir>/lidar_replay` (names at :157-162).
+Optionally continues into the ray-drop stage without the `.npy` round trip (rows f-2 / f-4): GPU range projection ->
+UNet feature stack -> UNet -> drop mask -> KITTI `.bin/.label`.
+
+Inputs are either a reference checkpoint (`--ckpt`, nerflidar_hip.checkpoints) or seeded synthetic weights of a named
+workload (`--workload`, there is no dataset or trained checkpoint in this image).  Sweep poses are synthetic
+(nerflidar_hip.lidar.synthetic_sweep); a dataset loader is outside the hot path.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import config as nconfig
+from . import lidar as nlidar
+from . import weights as nweights
+from .models import Model, render_image
+
+
+def render_sweep(model: Model, batch: Dict[str, np.ndarray], scale_factor: float, accelerator=None) -> Dict[str, torch.Tensor]:
+    """One sweep through `render_image(..., image=False)` + the LiDAR post-step (render_lidar.py:128,142-161).
+    Returns CUDA tensors: points [N,3] (metres), labels [N] int64, rgb [N,3], depth [N], semantic [N,K], intensity [N]."""
+    dev = model.device
+    tb = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in batch.items()}
+    r = render_image(model, accelerator, tb, False, model.config, image=False)
+    depth = r["depth"].reshape(-1)
+    out = dict(depth=depth, rgb=r["rgb"], semantic=r["semantic"],
+               points=(tb["origins"] + depth[:, None] * tb["directions"]) / scale_factor,
+               labels=torch.argmax(r["semantic"], dim=-1))
+    if "intensity" in r:
+        out["intensity"] = r["intensity"].reshape(-1)
+    return out
+
+
+def save_sweep(out_dir: str, idx: int, res: Dict[str, torch.Tensor]) -> None:
+    """File names and contents of render_lidar.py:157-162."""
+    os.makedirs(out_dir, exist_ok=True)
+    npy = lambda t: t.detach().cpu().numpy()
+    np.save(os.path.join(out_dir, "points_{:04d}.npy".format(idx)), npy(res["points"]))
+    np.save(os.path.join(out_dir, "points_semantic_{:04d}.npy".format(idx)), npy(res["labels"]))
+    np.save(os.path.join(out_dir, "points_rgb_{:04d}.npy".format(idx)), npy(res["rgb"]))
+
+
+def to_lidar_frame(points: torch.Tensor, origin_m: torch.Tensor, lidar2world: torch.Tensor) -> torch.Tensor:
+    """World metres -> sensor frame (what NeRF_Lidar_code/src/nerf2world.py:22-38 does with the stored lidar2global pose):
+    directions were built as d_world = d_lidar @ R^T, so p_lidar = (p_world - origin) @ R."""
+    return (points - origin_m[None, :]) @ lidar2world
+
+
+def drop_rays(res: Dict[str, torch.Tensor], points_lidar: torch.Tensor, unet, mask_thre: float = 0.5, place_car: bool = False,
+              width: int = 1024):
+    """Range image -> UNet features -> logits -> kept points/labels (rows f-2 + f-4), all on the GPU.  The range image is
+    32 x 1024 whatever the sweep's azimuth count (RD/lidar_utils.py:23)."""
+    from . import raydrop
+    proj = raydrop.range_projection(points_lidar.double(), semantic=res["labels"].float(), rgb=res["rgb"], H=32, W=width)
+    feats = raydrop.unet_features(proj, var=unet.n_channels == 6)
+    with torch.no_grad():
+        logits = unet(feats)
+    logits = logits[0] if isinstance(logits, tuple) else logits
+    return raydrop.apply_ray_drop(proj, logits[0], mask_thre=mask_thre, place_car=place_car), proj
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    src = ap.add_mutually_exclusive_group()
+    src.add_argument("--ckpt", help="reference checkpoint directory or file (checkpoint_<step>.ckpt)")
+    src.add_argument("--workload", default="C2", help="synthetic weights of a named workload (REF, C1, C2, C2S)")
+    ap.add_argument("--log2-hashmap", type=int, default=None, help="override the hash-map size of synthetic tables")
+    ap.add_argument("--num-nerf-samples", type=int, default=None)
+    ap.add_argument("--width", type=int, default=1024, help="azimuth columns per sweep (reference sweeps use 1100)")
+    ap.add_argument("--sweeps", type=int, default=1)
+    ap.add_argument("--scale-factor", type=float, default=1.0 / 250.0, help="scene_scale.npy of the reference (ZI/datasets.py:1233)")
+    ap.add_argument("--render-dir", default="render_out")
+    ap.add_argument("--precision", type=int, default=2, help="0 f32, 1 mixed, 2 fast (split-bf16 heads, bf16 view MLP)")
+    ap.add_argument("--raydrop-unet", default=None, help="UNet .pth (reference state_dict keys); enables the ray-drop stage")
+    ap.add_argument("--mask-thre", type=float, default=0.5)
+    ap.add_argument("--place-car", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise RuntimeError("render_lidar needs a GPU: the fused path has no CPU fallback")
+    if a.ckpt:
+        from .checkpoints import model_from_checkpoint
+        base = nconfig.ModelConfig()
+        if a.num_nerf_samples:
+            base.num_nerf_samples = a.num_nerf_samples
+        model, step, ignored = model_from_checkpoint(a.ckpt, base=base, precision=a.precision)
+        print(f"restored step {step}; {len(ignored)} keys outside the fused path ignored")
+    else:
+        mc = nconfig.workload(a.workload, a.log2_hashmap)
+        if a.num_nerf_samples:
+            mc.num_nerf_samples = a.num_nerf_samples
+        model = Model(mc, nweights.synth_state_dict(mc, seed=a.seed, trained_like=True), precision=a.precision)
+    unet = None
+    if a.raydrop_unet:
+        from . import raydrop
+        sd = torch.load(a.raydrop_unet, map_location="cpu", weights_only=True)
+        sd = sd.get("state_dict", sd)
+        n_ch = sd["inc.double_conv.0.weight"].shape[1]
+        unet = raydrop.UNet(n_ch, 2, bilinear="up1.up.weight" not in sd, regression="outr.conv.weight" in sd).to(model.device)
+        unet.load_state_dict(sd)
+        unet.eval()
+    out_dir = os.path.join(a.render_dir, "lidar_replay")
+    rot = torch.from_numpy(nlidar.seeded_rotation(a.seed)).float().to(model.device)
+    for idx in range(a.sweeps):
+        batch = nlidar.synthetic_sweep(width=a.width, seed=a.seed, scale_factor=a.scale_factor, sweep_idx=idx)
+        t0 = time.time()
+        res = render_sweep(model, batch, a.scale_factor)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        save_sweep(out_dir, idx, res)
+        n = res["points"].shape[0]
+        print(f"sweep {idx + 1}/{a.sweeps}: {n} rays in {dt:0.3f}s ({n / dt:,.0f} rays/s), {int(res['labels'].unique().numel())} labels")
+        if unet is not None:
+            from . import raydrop
+            origin_m = torch.from_numpy(batch["origins"][0]).to(model.device) / a.scale_factor
+            (pts, lab), _ = drop_rays(res, to_lidar_frame(res["points"], origin_m, rot), unet, a.mask_thre, a.place_car)
+            raydrop.write_points_and_labels(idx, os.path.join(a.render_dir, "raydrop"), pts, lab)
+            print(f"  ray-drop kept {pts.shape[0]} of {n} points")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
