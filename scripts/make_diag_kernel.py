@@ -41,11 +41,10 @@ s = sub(s, "    const bool valid = sample < P.M;\n",
         "    const bool valid = sample < P.M;\n    ns = 0;\n    STAMP();\n    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();\n")
 s = sub(s, "    if (h == 0 && valid) {\n        const float x = raw_density + P.density_bias;", "    STAMP();  // 1: trunk + heads done\n    if (h == 0 && valid) {\n        const float x = raw_density + P.density_bias;")
 s = sub(s, "    // ---- view MLP.", "    STAMP();  // 2: head outputs stored\n    // ---- view MLP.")
-s = sub(s, "        nlr_gemm<WT, (WT + BT + 1) * 2, 1, 8, P_V1 & 1>(", "        STAMP();  // 3: V0 done\n        nlr_gemm<WT, (WT + BT + 1) * 2, 1, 8, P_V1 & 1>(")
+s = sub(s, "        nlr_gemm_pipe<WT, (WT + BT + 1) * 2, 8, NPP, PIPE, P_V1 & 1>(", "        STAMP();  // 3: V0 done\n        nlr_gemm_pipe<WT, (WT + BT + 1) * 2, 8, NPP, PIPE, P_V1 & 1>(")
 s = sub(s, "        // hidden layers 2..D-1, two per iteration", "        STAMP();  // 4: V1 done\n        // hidden layers 2..D-1, two per iteration")
 s = sub(s, "        if (l < P.depth) {  // odd number of hidden layers", "        STAMP();  // 5: hidden pairs done\n        if (l < P.depth) {  // odd number of hidden layers")
-s = sub(s, "            [&](auto, auto, const f32x16 &a) { out1 = a; });\n    } else {",
-        "            [&](auto, auto, const f32x16 &a) { out1 = a; });\n        STAMP();  // 6: rgb layer done\n    } else {")
+s = sub(s, "    } else {\n        hbf[BT] = encf;", "        STAMP();  // 6: rgb layer done\n    } else {\n        hbf[BT] = encf;")
 s = sub(s, "    if (h == 0 && valid) {\n#pragma unroll\n        for (int c = 0; c < 3; ++c) {\n            const float z = P.rgb_premul",
         "    if (threadIdx.x == 0 && blockIdx.x < 4096 && P.inten && tile + gridDim.x >= ntiles) {\n"
         "        unsigned long long *dbg = (unsigned long long *)(P.inten + P.M) + (size_t)blockIdx.x * 16;\n"
