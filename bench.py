@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--log2-hashmap", type=int, default=None, help="shrink the hash tables (debug only)")
     ap.add_argument("--cpu-rays", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0, help="rays per nlr_render_rays call (0 = the whole sector at once; the "
+                    "reference's driver uses Config.render_chunk_size = 16384, ZI/configs.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +107,12 @@ def main():
     sf = 1.0 / 250.0
 
     def step():
-        r, _ = model.render_rays(batch, compute_extras=True, scale_factor=sf)
+        if args.chunk and args.chunk < n_rays:
+            parts = [model.render_rays({k: v[i:i + args.chunk] for k, v in batch.items()}, compute_extras=True, scale_factor=sf)[0]
+                     for i in range(0, n_rays, args.chunk)]
+            r = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+        else:
+            r, _ = model.render_rays(batch, compute_extras=True, scale_factor=sf)
         tile = sharding.pack_tile(r, H_BEAMS, wp)
         return sharding.gather_tiles(tile, width)
 

@@ -9,8 +9,9 @@
 //   ZI/math.py:89-108     sorted_interp (index form: xp, fp are non-decreasing)
 //   ZI/coord.py:103-162   power_transformation ray warp (s_to_t)
 // The reference materialises [N, 3S'+1, S'] and [N, S'+1, S] boolean masks in HBM; here a ray's
-// <= 3*256+1 fenceposts live in LDS, the sort is an in-LDS bitonic network, the CDF is a
-// wavefront scan and each sample does a binary search.
+// <= 3*512+1 fenceposts live in LDS, the sort is a 3-way merge by binary-search ranking, the dilation maximum a
+// range-max table query, the CDF a wavefront scan and each sample does a binary search.
+// Precondition (as in the reference's step functions): prev_sdist is non-decreasing along each ray.
 #include "nlr_kernels.h"
 
 struct ResampleParams {
@@ -27,7 +28,6 @@ struct ResampleParams {
     float lam, lam1, c_fwd, inv_exp;  // lambda, |lambda-1|, lam1/lambda, 1/lambda (as float)
     uint32_t N;
     float *sdist, *tdist;       // [N, S+1]
-    uint32_t n2;                // bitonic size (pow2 >= 3 n_prev + 1) when dilating
 };
 
 // ZI/coord.py:103-108 with x -> 2x (coord.py:145)
@@ -39,7 +39,7 @@ __device__ __forceinline__ float nlr_warp_inv(float y, float lam, float lam1, fl
     return ((powf(((y * lam) / lam1 + 1.0f) + NLR_EPS, inv_exp) - 1.0f) * lam1) / 2.0f;
 }
 
-// LDS carve (floats): t[n+1] | p[n] | U[n2] | W[3n]  (dilate)  then  cw[m+1] | cen[S]
+// LDS carve (floats): t[n+1] | p[n] | U[3n+2] | W[3n] | Mx[(LV-1) n]  (dilate)  then  cw[m+1] | cen[S]
 __global__ void __launch_bounds__(64) nlr_resample_kernel(ResampleParams P) {
     extern __shared__ __align__(16) float lds[];
     const uint32_t ray = blockIdx.x;
@@ -76,50 +76,70 @@ __global__ void __launch_bounds__(64) nlr_resample_kernel(ResampleParams P) {
             m = n;
             scratch = p + n;
         } else {
-            float *U = p + n;        // n2
-            float *W = U + P.n2;     // 3n
+            float *U = p + n;            // 3n+2
+            float *W = U + (3 * n + 2);  // 3n
+            float *Mx = W + 3 * n;       // (LV-1) * n: sparse table of range maxima over p (level 0 is p itself)
             const float d = P.dilation;
             // weight_to_pdf (stepfun.py:64-67)
             for (uint32_t j = lane; j < n; j += 64) p[j] = p[j] / fmaxf(t[j + 1] - t[j], NLR_EPS);
-            // cat([t, t0, t1]) padded with +inf (stepfun.py:77-79)
-            for (uint32_t i = lane; i < P.n2; i += 64) {
-                float v;
-                if (i <= n) v = t[i];
-                else if (i <= 2 * n) v = t[i - (n + 1)] - d;        // t0_j = t_j - d
-                else if (i <= 3 * n) v = t[i - (2 * n + 1) + 1] + d; // t1_j = t_{j+1} + d
-                else v = INFINITY;
-                U[i] = v;
-            }
-            __syncthreads();
-            // bitonic sort, ascending
-            for (uint32_t k = 2; k <= P.n2; k <<= 1) {
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = lane; i < P.n2; i += 64) {
-                        const uint32_t ixj = i ^ j;
-                        if (ixj > i) {
-                            const float a = U[i], b = U[ixj];
-                            const bool up = (i & k) == 0;
-                            if ((a > b) == up) {
-                                U[i] = b;
-                                U[ixj] = a;
-                            }
-                        }
-                    }
-                    __syncthreads();
+            // sort(cat([t, t0, t1])) (stepfun.py:77-79) with t0_j = t_j - d, t1_j = t_{j+1} + d.  The three lists are
+            // each non-decreasing (t is a step function's fenceposts; float add/sub of a constant is monotone), so the
+            // sort is a 3-way merge: an element's position is its index in its own list plus the number of elements of
+            // the other two lists that precede it (ties: t before t0 before t1), two binary searches per element
+            // instead of a 36-pass bitonic network.  The sorted VALUES are what a full sort gives.
+            auto count = [&](uint32_t len, auto pred) {  // #{i < len : pred(i)}, pred true on a prefix
+                uint32_t lo = 0, hi = len;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pred(mid)) lo = mid + 1; else hi = mid;
                 }
+                return lo;
+            };
+            for (uint32_t i = lane; i <= 3 * n; i += 64) {
+                float v;
+                uint32_t r;
+                if (i <= n) {
+                    v = t[i];
+                    r = i + count(n, [&](uint32_t q) { return (t[q] - d) < v; }) + count(n, [&](uint32_t q) { return (t[q + 1] + d) < v; });
+                } else if (i <= 2 * n) {
+                    const uint32_t o = i - (n + 1);
+                    v = t[o] - d;
+                    r = o + count(n + 1, [&](uint32_t q) { return t[q] <= v; }) + count(n, [&](uint32_t q) { return (t[q + 1] + d) < v; });
+                } else {
+                    const uint32_t o = i - (2 * n + 1);
+                    v = t[o + 1] + d;
+                    r = o + count(n + 1, [&](uint32_t q) { return t[q] <= v; }) + count(n, [&](uint32_t q) { return (t[q] - d) <= v; });
+                }
+                U[r] = fminf(fmaxf(v, 0.0f), 1.0f);  // clip to the domain [0,1] (stepfun.py:80)
             }
-            // clip to the domain [0,1] (stepfun.py:80)
-            const uint32_t nd = 3 * n + 1;
-            for (uint32_t i = lane; i < nd; i += 64) U[i] = fminf(fmaxf(U[i], 0.0f), 1.0f);
+            // range-maximum table: Mx[l-1][j] = max p[j .. j + 2^l - 1] (indices clamped to n-1)
+            uint32_t LV = 1;
+            while ((2u << (LV - 1)) <= n) ++LV;  // levels 0 .. LV-1, 2^(LV-1) <= n
             __syncthreads();
-            // max over covering intervals (stepfun.py:81-87), then pdf_to_weight (stepfun.py:70-72)
+            for (uint32_t l = 1; l < LV; ++l) {
+                const float *src = l == 1 ? p : Mx + (size_t)(l - 2) * n;
+                float *dst = Mx + (size_t)(l - 1) * n;
+                const uint32_t h2 = 1u << (l - 1);
+                for (uint32_t j = lane; j < n; j += 64) {
+                    const uint32_t j2 = j + h2 < n ? j + h2 : n - 1;
+                    dst[j] = fmaxf(src[j], src[j2]);
+                }
+                __syncthreads();
+            }
+            // max over covering intervals (stepfun.py:81-87): interval j covers t_k iff (t_j - d) <= t_k < (t_{j+1} + d);
+            // both bounds are monotone in j, so the covering set is the index range [j0, j1) found by two binary searches
+            // and its maximum comes from the table (the reference builds an [3n+1, n] mask).  Then pdf_to_weight
+            // (stepfun.py:70-72).
             float part = 0.0f;
             for (uint32_t k = lane; k < 3 * n; k += 64) {
                 const float tk = U[k];
+                const uint32_t j1 = count(n, [&](uint32_t q) { return (t[q] - d) <= tk; });
+                const uint32_t j0 = count(n, [&](uint32_t q) { return (t[q + 1] + d) <= tk; });
                 float best = 0.0f;
-                for (uint32_t j = 0; j < n; ++j) {
-                    const bool in = ((t[j] - d) <= tk) && ((t[j + 1] + d) > tk);
-                    best = fmaxf(best, in ? p[j] : 0.0f);
+                if (j0 < j1) {
+                    const uint32_t len = j1 - j0, l = 31u - (uint32_t)__clz((int)len);
+                    const float *row = l == 0 ? p : Mx + (size_t)(l - 1) * n;
+                    best = fmaxf(best, fmaxf(row[j0], row[j1 - (1u << l)]));
                 }
                 const float wk = best * (U[k + 1] - tk);
                 W[k] = wk;
@@ -133,7 +153,7 @@ __global__ void __launch_bounds__(64) nlr_resample_kernel(ResampleParams P) {
             tt = U + 1;
             ww = W + 1;
             m = 3 * n - 2;
-            scratch = W + 3 * n;
+            scratch = Mx + (size_t)(LV - 1) * n;
         }
     }
     __syncthreads();
@@ -253,12 +273,6 @@ extern "C" void nlr_sample_u(uint32_t n, int rand, float *u_host, float *max_jit
     }
 }
 
-static uint32_t next_pow2(uint32_t v) {
-    uint32_t p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-
 // Internal launcher shared by nlr_resample_level and nlr_render_rays (u_dev already uploaded).
 int nlr_launch_resample(const float *prev_sdist, const float *prev_weights, uint32_t n_prev, float dilation, float anneal,
                         float pad, uint32_t S, const float *u_dev, const float *jitter, float max_jitter, const float *near,
@@ -288,7 +302,6 @@ int nlr_launch_resample(const float *prev_sdist, const float *prev_weights, uint
     P.sdist = sdist;
     P.tdist = tdist;
     const bool dilate = n_prev > 0 && dilation > 0.0f;
-    P.n2 = dilate ? next_pow2(3 * n_prev + 1) : 0;
     size_t fl;
     uint32_t m;
     if (n_prev == 0) {
@@ -298,7 +311,9 @@ int nlr_launch_resample(const float *prev_sdist, const float *prev_weights, uint
         fl = 2 * (size_t)n_prev + 1;
         m = n_prev;
     } else {
-        fl = 2 * (size_t)n_prev + 1 + P.n2 + 3 * (size_t)n_prev;
+        uint32_t lv = 1;
+        while ((2u << (lv - 1)) <= n_prev) ++lv;
+        fl = 2 * (size_t)n_prev + 1 + (3 * (size_t)n_prev + 2) + 3 * (size_t)n_prev + (size_t)(lv - 1) * n_prev;
         m = 3 * n_prev - 2;
     }
     fl += (m + 1) + S + 8;
