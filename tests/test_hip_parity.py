@@ -141,6 +141,37 @@ def test_resample_with_dilation(name, S):
     assert (np.diff(sd, axis=-1) >= 0).all() and sd.min() >= 0 and sd.max() <= 1
 
 
+@pytest.mark.parametrize("n_prev,S", [(1, 16), (2, 8), (37, 48), (64, 64), (100, 32), (190, 64), (256, 128)])
+def test_resample_dilation_ties_and_odd_sizes(n_prev, S):
+    """The dilation stage ranks the merged fenceposts by binary search and takes window maxima from a range-max table:
+    exercise ties (repeated fenceposts = zero-width bins, fenceposts exactly `dilation` apart, values pinned at 0 and 1),
+    sizes that are not powers of two, and windows that span every interval, against the pinned oracle chain."""
+    rng = np.random.default_rng(100 + n_prev)
+    rows, d = 96, 0.03125  # a power of two: t_j - d == t_i and t_j + d == t_i happen exactly below
+    grid = np.arange(0, 65, dtype=np.float32) / 64  # multiples of 1/64 = d/2, exact in float
+    t = np.sort(rng.choice(grid, size=(rows, n_prev + 1), replace=True), axis=-1).astype(np.float32)
+    t[: rows // 3] = np.sort(rng.random((rows // 3, n_prev + 1)).astype(np.float32), axis=-1)  # generic rows
+    t[0, 0], t[0, -1] = 0.0, 1.0
+    t[1] = np.linspace(0.4, 0.4 + 1e-6, n_prev + 1, dtype=np.float32)  # everything inside one dilation window
+    w = rng.random((rows, n_prev)).astype(np.float32) + 1e-3
+    w[2] = 0.0
+    w[2, n_prev // 2] = 1.0  # one occupied bin
+    w = w / w.sum(-1, keepdims=True)
+    near, far = np.full((rows,), 0.008, np.float32), np.full((rows,), 2.0, np.float32)
+    sd, td = _resample(t, w, d, S, near, far)
+    tdil, wdil = orc.max_dilate_weights(T(t), T(w), d, (0., 1.), renormalize=True)
+    tdil, wdil = tdil[..., 1:-1], wdil[..., 1:-1]
+    if n_prev == 1:  # 3n-2 = 1 bin left after the trim
+        assert tdil.shape[-1] == 2
+    logits = torch.where(tdil[..., 1:] > tdil[..., :-1], torch.log(wdil), torch.full_like(wdil, -torch.inf))
+    ref_s = orc.sample_intervals(tdil, logits, S, (0., 1.))
+    ok = torch.isfinite(ref_s).all(-1).numpy()  # rows whose trimmed step function has no mass are NaN in the reference too
+    assert ok.sum() >= rows // 2
+    assert np.abs(sd[ok] - ref_s.numpy()[ok]).mean() <= 2e-6
+    np.testing.assert_allclose(sd[ok], ref_s.numpy()[ok], atol=2e-4, rtol=0)
+    assert (np.diff(sd[ok], axis=-1) >= 0).all()
+
+
 @pytest.mark.parametrize("name", _names("fn_sample_intervals"))
 def test_resample_plain(name):
     """No dilation: weights -> logits exactly as models.py:352-355 (fixtures carry log-weights)."""
