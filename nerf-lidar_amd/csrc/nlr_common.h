@@ -46,6 +46,8 @@ struct GridParams {
     uint32_t res[NLR_MAX_GRID_LEVELS];    // resolution = ceil(scale)+1 (cu:139)
     float scale[NLR_MAX_GRID_LEVELS];     // exp2f(l*S)*H-1 (cu:138)
     float gsize[NLR_MAX_GRID_LEVELS];     // grid_sizes[l] as float (grid.py:128-129,142)
+    float inv_gsize[NLR_MAX_GRID_LEVELS]; // 1.0f / gsize[l] (IEEE division on the host = the device's): a level constant,
+                                          // not 12 VALU instructions per lane per level
     uint32_t dense[NLR_MAX_GRID_LEVELS];  // 1 when the dense stride walk never exceeds hsize
     // Index mode per level, decided once on the host (the reference re-derives it per corner, gridencoder.cu:66-84):
     //   0 dense: x + y*s + z*s*s, always < hsize (no modulo);  1 hashed with a power-of-two table: & (hsize-1);

@@ -48,6 +48,7 @@ int nlr_fill_grid_params(GridParams *gp, const void *table, int table_dtype, con
         // grid_sizes buffer of grid.py:128-129,142: ceil(H * pls^l) (+1 unless align_corners)
         double r = ceil((double)H * exp2((double)l * (double)S));
         gp->gsize[l] = (float)((int)r + (align_corners ? 0 : 1));
+        gp->inv_gsize[l] = 1.0f / gp->gsize[l];
         uint64_t step = align_corners ? gp->res[l] : gp->res[l] + 1, stride = 1;
         int dense = 1;
         for (int d = 0; d < 3; ++d) {
