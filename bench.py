@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--log2-hashmap", type=int, default=None, help="shrink the hash tables (debug only)")
     ap.add_argument("--cpu-rays", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--table-dtype", choices=["f32", "f16"], default="f32", help="hash-table storage; f32 is the benchmark "
+                    "configuration, f16 is what the reference uses under autocast (Z/gridencoder/grid.py:43-44)")
     ap.add_argument("--chunk", type=int, default=0, help="rays per nlr_render_rays call (0 = the whole sector at once; the "
                     "reference's driver uses Config.render_chunk_size = 16384, ZI/configs.py)")
     args = ap.parse_args()
@@ -98,7 +100,8 @@ def main():
 
     mc = nconfig.workload(args.workload, args.log2_hashmap)
     sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
-    model = Model(mc, sd, device=dev, precision=args.precision)
+    model = Model(mc, sd, device=dev, precision=args.precision,
+                  table_dtype=torch.float16 if args.table_dtype == "f16" else torch.float32)
     width = W_COLS * world
     full = nlidar.synthetic_sweep(width=width, seed=0)
     sec, wp = nlidar.azimuth_sector(full, H_BEAMS, width, rank, world)
@@ -174,8 +177,12 @@ def main():
                       _lib.PREC_MIXED: "f32 (sampling, hash grid, density/semantic/intensity layers on f32 MFMA) + bf16 MFMA (view MLP)",
                       _lib.PREC_FAST: "f32 (sampling, hash grid) + split-bf16 x3 MFMA (density/semantic/intensity) + bf16 MFMA (view MLP)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: nuScenes 32-beam sweep, 32x1024 rays per GPU, samples (64,64,128), "
-                                   "8x256 NerfMLP + semantic + intensity heads, full-size fp32 hash tables",
+            "config": {"workload": f"{args.workload}: nuScenes 32-beam sweep, 32x1024 rays per GPU, samples "
+                                   f"({','.join(str(x) for x in mc.level_samples())}), "
+                                   f"{mc.nerf_mlp.net_depth_viewdirs}x{mc.nerf_mlp.net_width_viewdirs} NerfMLP + semantic"
+                                   f"{' + intensity' if mc.config.use_intensity else ''} heads, "
+                                   f"{'full-size' if args.log2_hashmap is None else f'2^{args.log2_hashmap}-entry'} "
+                                   f"{'fp32' if args.table_dtype == 'f32' else 'fp16'} hash tables",
                        "rays_per_gpu_per_step": n_rays, "azimuth_columns_total": width,
                        "parallelism": f"azimuth-sector x{world}" + (" + 1 all_gather of the packed range image" if world > 1 else ""),
                        "flops_per_ray": nflops.flops_per_ray(mc), "gather_bytes_per_ray": nflops.gather_bytes_per_ray(mc)},
