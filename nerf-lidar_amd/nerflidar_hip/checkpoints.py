@@ -166,3 +166,39 @@ def model_from_checkpoint(ckpt_dir_or_file, step=None, base: Optional[ModelConfi
     if any(k.startswith("obj_mlp") for k in ignored) and base is not None and base.config.instance_obj:
         raise NotImplementedError("checkpoint carries obj_mlp_* (dynamic-object branch, SURVEY 8f-1): outside the fused path")
     return Model(mc, keep, device=device, **model_kw), step, ignored
+
+
+def dynamic_model_from_checkpoint(ckpt_dir_or_file, tracks, class_names, step=None, base: Optional[ModelConfig] = None, device="cuda:0",
+                                  **model_kw):
+    """Checkpoint of a `Config.instance_obj=True` run (the shipped gin) -> `nerflidar_hip.objects.DynamicModel`.
+    The static field is imported as in `model_from_checkpoint`; `obj_mlp_<class id>.*` and `latent_vector_dict.obj_latent_<track>`
+    (ZI/models.py:150-173) feed the object branch, whose latent size and hash-map size are read off the tensors.
+    tracks [N_obj, T, 9] / class_names come from the dataset (`dataset.bboxes`), they are not stored in a checkpoint."""
+    from .config import obj_mlp_config
+    from .objects import DynamicModel, query_class
+    sd, step = load_checkpoint(ckpt_dir_or_file, step)
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    keep, ignored = split_state_dict(sd)
+    mc = infer_model_config(keep, base)
+    lat_keys = [k for k in sd if k.startswith("latent_vector_dict.obj_latent_")]
+    mc.config = dataclasses.replace(mc.config, instance_obj=True, latent_size=int(sd[lat_keys[0]].shape[0]) if lat_keys else 0)
+    mc.__post_init__()
+    cids = sorted({query_class(c) for c in class_names})
+    log2 = None
+    for cid in cids:
+        key = f"obj_mlp_{cid}.encoder.embeddings"
+        if key not in sd:
+            raise KeyError(f"checkpoint lacks {key} (class id {cid} of the given tracks)")
+        for cand in range(8, 29):
+            if int(grid_layout(obj_mlp_config(cid, mc.config.latent_size, cand))[0][-1]) == sd[key].shape[0]:
+                log2 = cand if log2 is None else log2
+                if cand != log2:
+                    raise ValueError("object networks with different hash-map sizes are not supported")
+                break
+        else:
+            raise ValueError(f"{key}: {sd[key].shape[0]} rows match no log2_hashmap_size")
+    used = dict(keep)
+    used.update({k: v for k, v in sd.items() if k.startswith(("obj_mlp_", "latent_vector_dict."))
+                 and not k.endswith((".encoder.idx", ".encoder.offsets", ".encoder.grid_sizes"))})
+    left = [k for k in ignored if not k.startswith(("obj_mlp_", "latent_vector_dict."))]
+    return DynamicModel(mc, used, tracks, class_names, device=device, obj_log2_hashmap=log2, **model_kw), step, left

@@ -42,6 +42,11 @@ class MLPConfig:
     use_intensity: bool = False
     no_sem_layer: bool = True
     re_weights: bool = True
+    # ObjMLP-only attributes (ZI/models.py:837-846); the defaults are those of MLP, i.e. inert for NerfMLP / PropMLP
+    fixed_semantic: bool = False
+    class_type: int = 255
+    latent_size: int = 0
+    split_latent: bool = False
 
     @property
     def grid_num_levels(self) -> int:
@@ -71,6 +76,7 @@ class Config:
     render_chunk_size: int = 16384
     sample_n_test: int = 7
     sample_m_test: int = 3
+    latent_size: int = 128  # nuscenes_single.gin:18
     near: float = 0.1
     far: float = 10.0
 
@@ -111,6 +117,17 @@ class ModelConfig:
 
     def level_samples(self) -> List[int]:
         return [int(s) for s in self.num_prop_samples[: self.num_levels - 1]] + [int(self.num_nerf_samples)]
+
+
+def obj_mlp_config(class_type: int = 255, latent_size: int = 128, log2_hashmap: int = 21, use_semantic: bool = True) -> MLPConfig:
+    """ObjMLP as `Model.__init__` builds it in latent mode (ZI/models.py:125-142) under the shipped gin
+    (nuscenes_single.gin:36-44): L = 7 levels x 2 features up to resolution 1024, bottleneck 64, view width 32, deg_view 2,
+    no ray warp, no erf re-weighting, one-hot semantic of the track's class, latent split into shape / texture halves."""
+    return MLPConfig(bottleneck_width=64, net_depth_viewdirs=2, net_width_viewdirs=32, deg_view=2, grid_level_dim=2,
+                     grid_base_resolution=16, grid_disired_resolution=1024, grid_log2_hashmap_size=log2_hashmap,
+                     disable_density_normals=True, disable_rgb=False, warp_fn=None, re_weights=False, fixed_semantic=True,
+                     class_type=class_type, use_semantic=use_semantic, use_intensity=False, no_sem_layer=True,
+                     latent_size=latent_size, split_latent=True)
 
 
 # Named workloads of BASELINE.json / SURVEY section 8 ---------------------------------------

@@ -41,11 +41,15 @@ def grid_layout(cfg: MLPConfig, input_dim: int = 3, align_corners: bool = False)
 def mlp_param_shapes(cfg: MLPConfig) -> List[Tuple[str, Tuple[int, int], bool]]:
     """(name, (out,in), kaiming) for every Linear of ZI/models.py:MLP.__init__ on the path."""
     feat = cfg.grid_num_levels * cfg.grid_level_dim
+    if cfg.latent_size > 0:  # models.py:881-885: the (shape half of the) latent code rides beside the grid features
+        feat += cfg.latent_size // 2 if cfg.split_latent else cfg.latent_size
     out = [("density_layer.0", (64, feat), False),
            ("density_layer.2", (1 if cfg.disable_rgb else cfg.bottleneck_width, 64), False)]
     if cfg.disable_rgb:
         return out
     in_rgb = cfg.bottleneck_width + cfg.dim_dir_enc  # models.py:920-926
+    if cfg.split_latent:
+        in_rgb += cfg.latent_size // 2  # texture half (models.py:924-925)
     last = in_rgb
     for i in range(cfg.net_depth_viewdirs):  # models.py:939-950
         out.append((f"lin_second_stage_{i}", (cfg.net_width_viewdirs, last), True))
@@ -53,7 +57,7 @@ def mlp_param_shapes(cfg: MLPConfig) -> List[Tuple[str, Tuple[int, int], bool]]:
         if i == cfg.skip_layer_dir:
             last += in_rgb
     out.append(("rgb_layer", (cfg.num_rgb_channels, last), False))
-    if cfg.use_semantic and not cfg.no_sem_layer:  # models.py:954-957
+    if cfg.use_semantic and not cfg.no_sem_layer and not cfg.fixed_semantic:  # models.py:954-957
         out += [("sem_layer.0", (64, cfg.bottleneck_width), False), ("sem_layer.2", (cfg.class_num, 64), False)]
     if cfg.use_intensity:  # models.py:958-961
         out += [("intensity_layer.0", (64, cfg.bottleneck_width), False), ("intensity_layer.2", (1, 64), False)]
@@ -106,4 +110,35 @@ def synth_state_dict(mc: ModelConfig, seed: int = 0, table_std: float = 1e-4,
                 w = w * np.float32(8.0)
             sd[f"{prefix}.{name}.weight"] = np.ascontiguousarray(w, np.float32)
             sd[f"{prefix}.{name}.bias"] = np.ascontiguousarray(b, np.float32)
+    return sd
+
+
+def synth_object_state_dict(obj_cfgs: Dict[int, MLPConfig], n_tracks: int, seed: int = 0, trained_like: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded parameters of the dynamic-object branch with the reference's key names (ZI/models.py:150-173): one
+    `obj_mlp_<class_id>.*` per class (latent mode) and one `latent_vector_dict.obj_latent_<track>` per track
+    (train_utils.py:459-471, normal init).  trained_like scales tables and the density row so that boxes contain both
+    empty and opaque space."""
+    sd: Dict[str, np.ndarray] = {}
+    for cid, cfg in obj_cfgs.items():
+        prefix = f"obj_mlp_{cid}"
+        offsets, sizes, _ = grid_layout(cfg)
+        table = synth.table_init(seed, f"{prefix}.encoder.embeddings", int(offsets[-1]), cfg.grid_level_dim, 1.0 if trained_like else 1e-4)
+        if trained_like:
+            for l in range(len(offsets) - 1):
+                table[offsets[l]:offsets[l + 1]] *= np.float32(2.0 ** (-0.5 * l))
+        sd[f"{prefix}.encoder.embeddings"] = table
+        sd[f"{prefix}.encoder.offsets"] = offsets
+        sd[f"{prefix}.encoder.grid_sizes"] = sizes
+        for name, (o, i), kaiming in mlp_param_shapes(cfg):
+            w, b = synth.linear_init(seed, f"{prefix}.{name}", o, i, kaiming)
+            if trained_like and name == "density_layer.2":
+                w[0] *= np.float32(300.0)
+                b[0] += np.float32(-6.0)
+            sd[f"{prefix}.{name}.weight"] = np.ascontiguousarray(w, np.float32)
+            sd[f"{prefix}.{name}.bias"] = np.ascontiguousarray(b, np.float32)
+    lat = max((c.latent_size for c in obj_cfgs.values()), default=0)
+    for t in range(n_tracks):
+        if lat:
+            u = synth.uniform(seed, 7000 + t, (2, lat), 1e-7, 1.0).astype(np.float64)
+            sd[f"latent_vector_dict.obj_latent_{t}"] = (np.sqrt(-2 * np.log(u[0])) * np.cos(2 * np.pi * u[1])).astype(np.float32)
     return sd

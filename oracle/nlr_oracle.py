@@ -434,11 +434,13 @@ def to_torch_sd(sd_np):
 
 def model_forward(sd_np, mc, batch: Dict[str, torch.Tensor], train_frac=1.0, compute_extras=True,
                   sample_n=7, sample_m=3, rand_jitter: Optional[List[torch.Tensor]] = None,
-                  rand_deg: Optional[List[torch.Tensor]] = None, encoders=None, sd_t=None):
+                  rand_deg: Optional[List[torch.Tensor]] = None, encoders=None, sd_t=None, objects=None):
     """Returns (renderings, ray_history) like the reference.  rand_* are per-level uniform draws
-    ([N,1] and [N,S,n]) replacing torch.rand for rand=True; None = deterministic."""
+    ([N,1] and [N,S,n]) replacing torch.rand for rand=True; None = deterministic.
+    objects: None (Config.instance_obj=False) or the dict made by `make_objects` (dynamic-object branch, row f-1)."""
     encoders = encoders or make_encoders(sd_np, mc)
     sd = sd_t or to_torch_sd(sd_np)
+    obj_pose = obj_get_pose(batch["timestamp"], objects["tracks"]) if objects is not None else None
     _, s_to_t = construct_ray_warps(batch["near"], batch["far"], mc.power_lambda)
     init_s_near, init_s_far = 0., 1.
     sdist = torch.cat([torch.full_like(batch["near"], init_s_near), torch.full_like(batch["far"], init_s_far)], dim=-1)
@@ -468,6 +470,8 @@ def model_forward(sd_np, mc, batch: Dict[str, torch.Tensor], train_frac=1.0, com
         prefix = f"prop_mlp_{i_level}" if is_prop else "nerf_mlp"
         cfg = mc.prop_cfg(i_level) if is_prop else mc.nerf_mlp
         res = mlp_forward(sd, prefix, cfg, encoders[prefix], means, stds, batch["viewdirs"])
+        if objects is not None:
+            obj_merge(res, objects, sd, batch, tdist, obj_pose)
         weights = compute_alpha_weights(res["density"], tdist, batch["directions"], mc.opaque_background)
         bg = mc.bg_intensity_range[0] if mc.bg_intensity_range[0] == mc.bg_intensity_range[1] else \
             (mc.bg_intensity_range[0] + mc.bg_intensity_range[1]) / 2
@@ -479,6 +483,132 @@ def model_forward(sd_np, mc, batch: Dict[str, torch.Tensor], train_frac=1.0, com
         res.update(sdist=sdist.clone(), weights=weights.clone(), tdist=tdist.clone())
         ray_history.append(res)
     return renderings, ray_history
+
+
+# --------------------------------------------------------------------------------------------
+# f-1  dynamic-object branch (ZI/models.py:93-177,306-315,401-477; ZI/obj_utils.py:5-28,76-113,116-234,431-475)
+# --------------------------------------------------------------------------------------------
+def obj_get_pose(time, tracks):
+    """obj_utils.py:431-475.  time [N,1]; tracks [N_obj, T, 9] = (center3, theta_z, wlh3, timestamp, track_id) -> [N, N_obj, 9]:
+    the two recorded poses closest in time, blended with weight |t - t2| / (|t1 - t2| + 1e-9) clamped to [0,1] on the closest."""
+    time_diff = torch.abs(time[..., None] - tracks[:, :, -2].unsqueeze(0))
+    _, indices = torch.sort(time_diff, dim=-1)
+    closest = indices[..., :2]
+    n, n_obj, n_info = time.shape[0], tracks.shape[0], tracks.shape[-1]
+    time_expand = time.unsqueeze(-1).expand(-1, n_obj, n_info)
+    t_expand = tracks[:, :, -2].unsqueeze(0).expand(n, -1, -1)
+    tracks_expand = tracks.unsqueeze(0).expand(n, -1, -1, -1)
+    ci = closest.unsqueeze(-1).expand(-1, -1, -1, n_info)
+    t1 = torch.gather(t_expand, dim=-1, index=ci[..., 0, :]).squeeze(-1)
+    t2 = torch.gather(t_expand, dim=-1, index=ci[..., 1, :]).squeeze(-1)
+    # (sic) t_expand has T columns and the index n_info columns: the gather yields [N, N_obj, n_info] copies of the two times
+    total = torch.abs(t1 - t2) + 1e-9
+    w1 = (torch.abs(time_expand - t2) / total).clamp(0, 1)
+    w2 = 1 - w1
+    info1 = torch.gather(tracks_expand, dim=-2, index=ci[..., 0, :].unsqueeze(-2)).squeeze(dim=-2)
+    info2 = torch.gather(tracks_expand, dim=-2, index=ci[..., 1, :].unsqueeze(-2)).squeeze(dim=-2)
+    return w1 * info1 + w2 * info2
+
+
+def obj_rotate_yaw_z(p, yaw):
+    """obj_utils.py:76-113 with pitch=None.  (sic) p_y is computed from the ALREADY ROTATED p_x (line 106-107)."""
+    c, sn = torch.cos(yaw), torch.sin(yaw)
+    px = c * p[..., 0] - sn * p[..., 1]
+    py = sn * px + c * p[..., 1]
+    return torch.stack([px, py, p[..., 2]], dim=-1)
+
+
+def obj_scale_frames(p, sc_factor):
+    """obj_utils.py:5-28 (forward): p / (dim/2 + 1e-9), written as the reference multiplies."""
+    dim = torch.tensor([1., 1., 1.]) * sc_factor
+    return (1 / (dim / 2 + 1e-9)) * p
+
+
+def obj_box_pts(pts, viewdirs, obj_pose):
+    """obj_utils.py:203-234 + world2object :116-176 (inverse=False).  pts [N,S,3], viewdirs [N,3], obj_pose [N,N_obj,9] ->
+    pts_o, dirs_o [N,S,N_obj,3] in box coordinates ([-1,1]^3 inside), intersection_map [N,S,N_obj] bool."""
+    N, S = pts.shape[:2]
+    center, theta_z, wlh = obj_pose[:, :, :3], obj_pose[:, :, 3], obj_pose[:, :, 4:7]
+    pose = torch.repeat_interleave(center, S, dim=0)
+    th = torch.repeat_interleave(theta_z, S, dim=0)
+    dim = torch.repeat_interleave(wlh, S, dim=0)
+    dirs = torch.repeat_interleave(viewdirs, S, dim=0)
+    p = pts.reshape(-1, 3)
+    t_w_o = obj_rotate_yaw_z(-pose, th)
+    n_obj = th.shape[1]
+    pts_w = torch.repeat_interleave(p.unsqueeze(1), n_obj, dim=1)
+    dirs_w = torch.repeat_interleave(dirs.unsqueeze(1), n_obj, dim=1)
+    pts_o = obj_scale_frames(obj_rotate_yaw_z(pts_w, th) + t_w_o, dim)
+    dirs_o = obj_scale_frames(obj_rotate_yaw_z(dirs_w, th), dim)
+    dirs_o = dirs_o / torch.norm(dirs_o, dim=-1, keepdim=True)
+    imap = (pts_o[..., 0].abs() < 1) & (pts_o[..., 1].abs() < 1) & (pts_o[..., 2].abs() < 1)
+    return pts_o.reshape(N, S, -1, 3), dirs_o.reshape(N, S, -1, 3), imap.reshape(N, S, -1)
+
+
+def obj_mlp_forward(sd, prefix, cfg, enc, pts, viewdirs, latent):
+    """MLP.forward (ZI/models.py:1036-1265) as configured for ObjMLP: points without a multisample axis and zero std
+    (models.py:424-425), warp_fn None, re_weights False, latent split into shape / texture halves, fixed one-hot semantic."""
+    F = torch.nn.functional
+    feats = enc(pts, bound=1)  # [n, L*C]; unflatten/flatten of models.py:971,976 is the identity on values
+    if latent is not None:
+        feats = torch.cat([feats, latent[..., :cfg.latent_size // 2] if cfg.split_latent else latent], dim=-1)
+    x = _lin(sd, f"{prefix}.density_layer.2", F.relu(_lin(sd, f"{prefix}.density_layer.0", feats)))
+    out = dict(density=F.softplus(x[..., 0] + cfg.density_bias), semantic=None, intensity=None)
+    if cfg.use_semantic:  # fixed_semantic (models.py:1125-1130)
+        sem = torch.zeros(x.shape[:-1] + (cfg.class_num,))
+        if cfg.class_type != 255:
+            sem[..., cfg.class_type] = 1.
+        out["semantic"] = sem
+    h = [x, pos_enc(viewdirs, 0, cfg.deg_view)]
+    if cfg.split_latent:
+        h.append(latent[..., cfg.latent_size // 2:])
+    h = torch.cat(h, dim=-1)
+    inputs = h
+    for i in range(cfg.net_depth_viewdirs):
+        h = F.relu(_lin(sd, f"{prefix}.lin_second_stage_{i}", h))
+        if i == cfg.skip_layer_dir:
+            h = torch.cat([h, inputs], dim=-1)
+    rgb = torch.sigmoid(cfg.rgb_premultiplier * _lin(sd, f"{prefix}.rgb_layer", h) + cfg.rgb_bias)
+    out["rgb"] = rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
+    return out
+
+
+def make_objects(sd_np, tracks, class_ids, obj_cfgs):
+    """tracks [N_obj,T,9] numpy; class_ids[track] -> class id (obj_utils.query_class); obj_cfgs {class id: MLPConfig}."""
+    encs = {}
+    for cid, cfg in obj_cfgs.items():
+        L = cfg.grid_num_levels
+        pls = np.exp2(np.log2(cfg.grid_disired_resolution / cfg.grid_base_resolution) / (L - 1))
+        pre = f"obj_mlp_{cid}"
+        encs[cid] = GridEncoder(sd_np[f"{pre}.encoder.embeddings"], sd_np[f"{pre}.encoder.offsets"], sd_np[f"{pre}.encoder.grid_sizes"],
+                                pls, cfg.grid_base_resolution)
+    return dict(tracks=torch.from_numpy(np.asarray(tracks, np.float32)), class_ids=list(class_ids), cfgs=obj_cfgs, encoders=encs)
+
+
+def obj_merge(res, objects, sd, batch, tdist, obj_pose):
+    """ZI/models.py:401-477 (latent mode, no symmetry): evaluate each track's ObjMLP on the samples inside its box and
+    overwrite the static field's per-sample results there; later tracks win where boxes overlap."""
+    t_mids = 0.5 * (tdist[..., :-1] + tdist[..., 1:])
+    pts_w = t_mids[..., None] * batch["directions"][:, None, :] + batch["origins"][:, None, :]
+    pts_o, dirs_o, imap = obj_box_pts(pts_w, batch["viewdirs"], obj_pose)
+    for track_id, cid in enumerate(objects["class_ids"]):
+        m = imap[:, :, track_id]
+        if m.sum() == 0:
+            continue
+        cfg = objects["cfgs"][cid]
+        pts_k, dirs_k = pts_o[m][:, track_id, :], dirs_o[m][:, track_id, :]
+        latent = sd[f"latent_vector_dict.obj_latent_{track_id}"][None, :].repeat(pts_k.shape[0], 1)
+        o = obj_mlp_forward(sd, f"obj_mlp_{cid}", cfg, objects["encoders"][cid], pts_k, dirs_k, latent)
+        for key in ("density", "rgb", "semantic", "intensity"):
+            if res.get(key) is None:
+                continue
+            if o[key] is None:  # the reference assigns None into a tensor here (TypeError): an invalid configuration
+                raise TypeError(f"static field predicts '{key}' but ObjMLP does not")
+            tmp = torch.zeros_like(res[key])
+            tmp[m] = o[key]
+            mm = m if m.shape == res[key].shape else m[..., None].expand(res[key].shape)
+            res[key] = torch.where(mm, tmp, res[key])
+    res["obj_mask"] = imap.sum(-1) > 0
 
 
 def lidar_post(batch, rendering, scale_factor):

@@ -375,6 +375,74 @@ def gen_unet():
             save(f"unet_{tag}", x=x, logits=out)
 
 
+def gen_objects():
+    """Row f-1: the reference `Model` with Config.instance_obj=True (latent mode, shipped ObjMLP gin bindings) on a sweep with
+    three synthetic tracks; per-function fixtures for get_pose / box_pts and the whole forward."""
+    print("dynamic-object fixtures")
+    from internal import obj_utils as robj
+    from nerflidar_hip import objects as nobj
+    lg, width, seed = 12, 16, 2
+    mc = nconfig.workload("REF", lg)
+    beams = nlidar.LIDAR_ANGLES[::8][:4]
+    batch_np = nlidar.synthetic_sweep(width=width, seed=seed, beams=beams)
+    N = batch_np["origins"].shape[0]
+    batch_np["timestamp"] = nobj.synthetic_timestamps(N, seed)
+    names = ["vehicle.car", "vehicle.truck", "vehicle.car"]
+    tracks = nobj.synthetic_tracks(batch_np, n_tracks=3, n_times=5, seed=seed)
+    cids = [robj.query_class(c) for c in names]
+    assert cids == [nobj.query_class(c) for c in names]
+    obj_cfgs = {cid: nconfig.obj_mlp_config(cid, latent_size=128, log2_hashmap=lg) for cid in sorted(set(cids))}
+    sd_np = nweights.synth_state_dict(mc, seed=seed, trained_like=True)
+    sd_np.update(nweights.synth_object_state_dict(obj_cfgs, len(names), seed=seed))
+    # gin bindings of nuscenes_single.gin:36-44 (+ the small hash map of this fixture) as class attributes
+    for k, v in dict(disable_rgb=False, grid_disired_resolution=1024, density_init=True, disable_density_normals=True, obj_mode=False,
+                     bottleneck_width=64, grid_level_dim=2, net_width_viewdirs=32, split_latent=True, grid_log2_hashmap_size=lg).items():
+        setattr(rmodels.ObjMLP, k, v)
+    for cls, cfg in ((rmodels.NerfMLP, mc.nerf_mlp), (rmodels.PropMLP, mc.prop_mlp)):
+        for f in ("bottleneck_width", "net_depth_viewdirs", "net_width_viewdirs", "skip_layer_dir", "deg_view", "disable_density_normals",
+                  "disable_rgb", "grid_level_dim", "grid_base_resolution", "grid_disired_resolution", "grid_log2_hashmap_size", "class_num"):
+            setattr(cls, f, getattr(cfg, f))
+    c = mc.config
+    cfg_ns = types.SimpleNamespace(use_semantic=c.use_semantic, analytic_gradient=c.analytic_gradient, use_intensity=c.use_intensity,
+                                   no_sem_layer=c.no_sem_layer, zero_glo=True, instance_obj=True, sem_detach=True,
+                                   vis_num_rays=c.vis_num_rays, hash_decay_mults=0, symmetrize=False, latent_size=128, fuse_render=False)
+    bboxes = ({i: tracks[i] for i in range(len(names))}, {i: names[i] for i in range(len(names))})
+    latents = {f"obj_latent_{i}": nn.Parameter(torch.from_numpy(sd_np[f"latent_vector_dict.obj_latent_{i}"])) for i in range(len(names))}
+    model = rmodels.Model(config=cfg_ns, raydist_fn=mc.raydist_fn, opaque_background=mc.opaque_background,
+                          num_prop_samples=tuple(mc.num_prop_samples), num_nerf_samples=mc.num_nerf_samples, num_levels=mc.num_levels,
+                          prop_desired_grid_size=list(mc.prop_desired_grid_size), bboxes=bboxes, latent_vector_dict=latents)
+    ref_sd = model.state_dict()
+    new_sd = {}
+    for k, v in ref_sd.items():
+        if k.endswith(".idx"):
+            continue
+        assert k in sd_np, f"reference key {k} missing from the synthetic state_dict"
+        t = torch.from_numpy(np.ascontiguousarray(sd_np[k]))
+        assert tuple(t.shape) == tuple(v.shape), (k, t.shape, v.shape)
+        new_sd[k] = t.to(v.dtype)
+    assert not (set(sd_np) - set(ref_sd)), set(sd_np) - set(ref_sd)
+    model.load_state_dict(new_sd, strict=False)
+    model.eval()
+    batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    with torch.no_grad():
+        pose = robj.get_pose(batch["timestamp"], model.tracks)
+        rend, hist = model(False, batch, train_frac=1.0, compute_extras=True, zero_glo=True)
+        tdist = hist[-1]["tdist"]
+        t_mid = 0.5 * (tdist[..., :-1] + tdist[..., 1:])
+        pts_w = t_mid[..., None] * batch["directions"][:, None, :] + batch["origins"][:, None, :]
+        pts_o, dirs_o, imap = robj.box_pts(pts=pts_w, viewdirs=batch["viewdirs"], obj_pose=pose, sym=False)
+    out = {"out_" + k: v for k, v in rend[-1].items() if not k.startswith("ray_")}
+    for lvl, h in enumerate(hist):
+        for k in ("sdist", "tdist", "weights", "density", "obj_mask"):
+            out[f"hist{lvl}_{k}"] = h[k]
+        out[f"lvl{lvl}_depth"] = rend[lvl]["depth"]
+    out["hist2_rgb"], out["hist2_semantic"] = hist[-1]["rgb"], hist[-1]["semantic"]
+    assert int(imap.sum()) > 50 and all(int(hist[l]["obj_mask"].sum()) > 0 for l in range(3)), "tracks must intersect samples"
+    save("obj_REF_small", log2_hashmap=np.array(lg), seed=np.array(seed), width=np.array(width), beams=np.array(beams),
+         tracks=tracks, class_ids=np.array(cids), timestamp=batch_np["timestamp"], pose=pose, pts_w=pts_w, pts_o=pts_o, dirs_o=dirs_o,
+         imap=imap, **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -385,4 +453,5 @@ if __name__ == "__main__":
     gen_unet()
     gen_camera()
     gen_range_image()
+    gen_objects()
     print("done")

@@ -1,0 +1,181 @@
+"""Scope row f-1: dynamic-object branch (Config.instance_obj=True).  The fixture `obj_REF_small` is the reference's own
+Model.forward with three tracks (tests/golden/make_golden.py:gen_objects); the oracle restatement is held to it on the CPU, the
+GPU path (fused static stages + torch ObjMLPs, nerflidar_hip/objects.py) to the fixture and to the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from nerflidar_hip import config as nconfig, lidar as nlidar, objects as nobj, weights as nweights
+from oracle import nlr_oracle as orc
+
+NAMES = ["vehicle.car", "vehicle.truck", "vehicle.car"]
+
+
+def _scene(g):
+    lg, seed, width = int(g["log2_hashmap"]), int(g["seed"]), int(g["width"])
+    mc = nconfig.workload("REF", lg)
+    b = nlidar.synthetic_sweep(width=width, seed=seed, beams=list(g["beams"]))
+    b["timestamp"] = g["timestamp"]
+    cids = [int(c) for c in g["class_ids"]]
+    cfgs = {cid: nconfig.obj_mlp_config(cid, latent_size=128, log2_hashmap=lg) for cid in sorted(set(cids))}
+    sd = nweights.synth_state_dict(mc, seed=seed, trained_like=True)
+    sd.update(nweights.synth_object_state_dict(cfgs, len(cids), seed=seed))
+    return mc, b, cids, cfgs, sd
+
+
+def test_synthetic_scene_is_the_fixtures():
+    g = golden("obj_REF_small")
+    mc, b, cids, cfgs, sd = _scene(g)
+    np.testing.assert_array_equal(nobj.synthetic_tracks(b, 3, 5, int(g["seed"])), g["tracks"])
+    np.testing.assert_array_equal(nobj.synthetic_timestamps(b["origins"].shape[0], int(g["seed"])), g["timestamp"])
+    assert cids == [nobj.query_class(c) for c in NAMES] == [13, 14, 13]
+    assert [nobj.query_class(c) for c in ("human.pedestrian.adult", "vehicle.bus.rigid", "vehicle.trailer", "movable_object.barrier")] == [11, 15, 14, 255]
+
+
+def test_oracle_pose_and_box_transform_match_reference():
+    g = golden("obj_REF_small")
+    pose = orc.obj_get_pose(torch.from_numpy(g["timestamp"]), torch.from_numpy(g["tracks"]))
+    np.testing.assert_allclose(pose.numpy(), g["pose"], rtol=0, atol=1e-7)
+    b = nlidar.synthetic_sweep(width=int(g["width"]), seed=int(g["seed"]), beams=list(g["beams"]))
+    pts_o, dirs_o, imap = orc.obj_box_pts(torch.from_numpy(g["pts_w"]), torch.from_numpy(b["viewdirs"]), torch.from_numpy(g["pose"]))
+    np.testing.assert_array_equal(imap.numpy(), g["imap"])
+    np.testing.assert_allclose(pts_o.numpy(), g["pts_o"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dirs_o.numpy(), g["dirs_o"], rtol=1e-6, atol=1e-6)
+    # the same two functions as the product path writes them (torch, device-agnostic)
+    pose2 = nobj.get_pose(torch.from_numpy(g["timestamp"]), torch.from_numpy(g["tracks"]))
+    np.testing.assert_allclose(pose2.numpy(), g["pose"], rtol=0, atol=1e-7)
+    p2, d2, m2 = nobj.box_pts(torch.from_numpy(g["pts_w"]), torch.from_numpy(b["viewdirs"]), pose2)
+    np.testing.assert_array_equal(m2.numpy(), g["imap"])
+    np.testing.assert_allclose(p2.numpy(), g["pts_o"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(d2.numpy(), g["dirs_o"], rtol=1e-6, atol=1e-6)
+
+
+def test_oracle_forward_with_objects_matches_reference():
+    g = golden("obj_REF_small")
+    mc, b, cids, cfgs, sd = _scene(g)
+    objs = orc.make_objects(sd, g["tracks"], cids, cfgs)
+    with torch.no_grad():
+        rend, hist = orc.model_forward(sd, mc, {k: torch.from_numpy(v) for k, v in b.items()}, objects=objs)
+    for lvl in range(3):
+        np.testing.assert_array_equal(hist[lvl]["obj_mask"].numpy(), g[f"hist{lvl}_obj_mask"])
+        np.testing.assert_allclose(hist[lvl]["sdist"].numpy(), g[f"hist{lvl}_sdist"], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(hist[lvl]["density"].numpy(), g[f"hist{lvl}_density"], atol=1e-3, rtol=2e-4)
+        np.testing.assert_allclose(rend[lvl]["depth"].numpy(), g[f"lvl{lvl}_depth"], atol=2e-5, rtol=0)
+    assert g["hist2_obj_mask"].sum() > 100 and g["hist0_obj_mask"].sum() > 100
+    np.testing.assert_allclose(hist[2]["rgb"].numpy(), g["hist2_rgb"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(hist[2]["semantic"].numpy(), g["hist2_semantic"], atol=2e-5, rtol=0)
+    for k in ("rgb", "depth", "semantic", "acc"):
+        np.testing.assert_allclose(rend[-1][k].numpy(), g["out_" + k], atol=2e-5, rtol=0, err_msg=k)
+    np.testing.assert_array_equal(rend[-1]["semantic"].numpy().argmax(-1), g["out_semantic"].argmax(-1))
+    # the objects matter: without them the rendering is different on the rays that cross a box
+    with torch.no_grad():
+        r0, _ = orc.model_forward(sd, mc, {k: torch.from_numpy(v) for k, v in b.items()})
+    hit = g["hist2_obj_mask"].any(-1)
+    assert np.abs(r0[-1]["depth"].numpy() - g["out_depth"])[hit].max() > 1e-3
+
+
+def test_object_parameter_shapes_are_the_references():
+    cfg = nconfig.obj_mlp_config(13, latent_size=128, log2_hashmap=21)
+    assert cfg.grid_num_levels == 7 and cfg.dim_dir_enc == 15
+    assert dict((n, s) for n, s, _ in nweights.mlp_param_shapes(cfg)) == {
+        "density_layer.0": (64, 14 + 64), "density_layer.2": (64, 64), "lin_second_stage_0": (32, 64 + 15 + 64),
+        "lin_second_stage_1": (32, 32 + 143), "rgb_layer": (3, 32)}
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_dynamic_model_matches_reference(precision):
+    g = golden("obj_REF_small")
+    mc, b, cids, cfgs, sd = _scene(g)
+    mc.config.instance_obj = True
+    model = nobj.DynamicModel(mc, sd, g["tracks"], NAMES, precision=precision, obj_log2_hashmap=int(g["log2_hashmap"]))
+    batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    rend, hist = model(False, batch, train_frac=1.0, compute_extras=True)
+    npy = lambda t: t.detach().cpu().numpy()
+    for lvl in range(3):
+        # a sample exactly on a box face can fall on either side after 1-ulp differences in tdist: allow a handful
+        assert (npy(hist[lvl]["obj_mask"]) != g[f"hist{lvl}_obj_mask"]).sum() <= 2
+        assert np.abs(npy(rend[lvl]["depth"]) - g[f"lvl{lvl}_depth"]).mean() <= 1e-3
+    d = np.abs(npy(rend[-1]["depth"]) - g["out_depth"])
+    assert d.mean() <= 1e-3 and np.percentile(d, 95) <= 1e-3          # north_star gate: depth L1 <= 1e-3
+    np.testing.assert_array_equal(npy(rend[-1]["semantic"]).argmax(-1), g["out_semantic"].argmax(-1))
+    assert np.abs(npy(rend[-1]["semantic"]) - g["out_semantic"]).max() <= 2e-3
+    assert np.abs(npy(rend[-1]["rgb"]) - g["out_rgb"]).mean() <= (2e-4 if precision == 0 else 3e-3)
+    assert 14 in set(g["out_semantic"].argmax(-1).tolist())  # a truck is visible: the object branch decides labels
+    # curr_track (models.py:307-313): moving every box far away must give the static rendering
+    far_tracks = g["tracks"].copy()
+    far_tracks[:, :, :3] += 50.0
+    r_far, h_far = model(False, batch, train_frac=1.0, compute_extras=True, curr_track=far_tracks)
+    from nerflidar_hip.models import Model
+    static = Model(nconfig.workload("REF", int(g["log2_hashmap"])), sd, precision=precision)
+    r_st, _ = static(False, batch, train_frac=1.0, compute_extras=True)
+    assert not bool(h_far[-1]["obj_mask"].any())
+    assert torch.equal(r_far[-1]["depth"], r_st[-1]["depth"]) and torch.equal(r_far[-1]["semantic"], r_st[-1]["semantic"])
+
+
+@pytest.mark.gpu
+def test_dynamic_model_rejects_what_the_reference_cannot_run():
+    g = golden("obj_REF_small")
+    mc, b, cids, cfgs, sd = _scene(g)
+    mc2 = nconfig.workload("C2", int(g["log2_hashmap"]))
+    sd2 = nweights.synth_state_dict(mc2, seed=0)
+    sd2.update({k: v for k, v in sd.items() if k.startswith(("obj_mlp", "latent"))})
+    with pytest.raises(NotImplementedError, match="intensity"):
+        nobj.DynamicModel(mc2, sd2, g["tracks"], NAMES, obj_log2_hashmap=int(g["log2_hashmap"]))
+    model = nobj.DynamicModel(mc, sd, g["tracks"], NAMES, obj_log2_hashmap=int(g["log2_hashmap"]))
+    batch = {k: torch.from_numpy(v).cuda() for k, v in b.items() if k != "timestamp"}
+    with pytest.raises(RuntimeError, match="timestamp"):
+        model.render_rays(batch)
+    with pytest.raises(ValueError, match="class name"):
+        nobj.DynamicModel(mc, sd, g["tracks"], NAMES[:2], obj_log2_hashmap=int(g["log2_hashmap"]))
+
+
+@pytest.mark.gpu
+def test_dynamic_model_from_checkpoint(tmp_path):
+    from nerflidar_hip import checkpoints as ck
+    g = golden("obj_REF_small")
+    mc, b, cids, cfgs, sd = _scene(g)
+    extra = dict(sd)
+    extra["glo_vecs.weight"] = np.zeros((4, 4), np.float32)
+    ck.save_checkpoint(tmp_path, extra, 77)
+    base = nconfig.ModelConfig(num_prop_samples=(64, 64), num_nerf_samples=32)
+    m2, step, left = ck.dynamic_model_from_checkpoint(tmp_path, g["tracks"], NAMES, base=base, precision=1)
+    assert step == 77 and left == ["glo_vecs.weight"] and m2.mc.config.latent_size == 128
+    mc.config.instance_obj = True
+    m1 = nobj.DynamicModel(mc, sd, g["tracks"], NAMES, precision=1, obj_log2_hashmap=int(g["log2_hashmap"]))
+    batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    r1, r2 = m1.render_rays(batch)[0], m2.render_rays(batch)[0]
+    for k in ("depth", "rgb", "semantic"):
+        assert torch.equal(r1[k], r2[k]), k
+
+
+@pytest.mark.gpu
+def test_overlapping_boxes_last_track_wins():
+    """Two boxes on the same spot with different classes: the reference's track loop lets the later one overwrite the earlier
+    (ZI/models.py:415,475); the product path evaluates only the winner - same result, checked against the oracle's loop."""
+    g = golden("obj_REF_small")
+    mc, b, cids, cfgs, sd = _scene(g)
+    tracks = g["tracks"].copy()
+    tracks[1] = tracks[0]          # the truck sits exactly on car 0
+    tracks[1, :, -1] = 1
+    tracks[2, :, :3] = tracks[0, :, :3] + 0.03   # car 2 overlaps both partly
+    objs = orc.make_objects(sd, tracks, cids, cfgs)
+    with torch.no_grad():
+        rend_o, hist_o = orc.model_forward(sd, mc, {k: torch.from_numpy(v) for k, v in b.items()}, objects=objs)
+    mc.config.instance_obj = True
+    model = nobj.DynamicModel(mc, sd, tracks, NAMES, precision=0, obj_log2_hashmap=int(g["log2_hashmap"]))
+    rend, hist = model(False, {k: torch.from_numpy(v).cuda() for k, v in b.items()}, train_frac=1.0, compute_extras=True)
+    npy = lambda t: t.detach().cpu().numpy()
+    assert int(hist_o[-1]["obj_mask"].sum()) > 50
+    for lvl in range(3):
+        assert (npy(hist[lvl]["obj_mask"]) != hist_o[lvl]["obj_mask"].numpy()).sum() <= 2
+    same = npy(hist[-1]["obj_mask"]) == hist_o[-1]["obj_mask"].numpy()
+    m = hist_o[-1]["obj_mask"].numpy() & same
+    # inside the boxes the per-sample semantic is the winner's one-hot: identical class per sample
+    np.testing.assert_array_equal(npy(hist[-1]["semantic"])[m].argmax(-1), hist_o[-1]["semantic"].numpy()[m].argmax(-1))
+    assert set(hist_o[-1]["semantic"].numpy()[m].argmax(-1).tolist()) == {13, 14} or set(hist_o[-1]["semantic"].numpy()[m].argmax(-1).tolist()) == {13}
+    d = np.abs(npy(rend[-1]["depth"]) - rend_o[-1]["depth"].numpy())
+    assert d.mean() <= 1e-3
+    np.testing.assert_array_equal(npy(rend[-1]["semantic"]).argmax(-1), rend_o[-1]["semantic"].numpy().argmax(-1))
