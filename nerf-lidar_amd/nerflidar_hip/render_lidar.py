@@ -85,10 +85,32 @@ def main(argv=None) -> int:
     ap.add_argument("--mask-thre", type=float, default=0.5)
     ap.add_argument("--place-car", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--tracks", default=None, help=".npy [N_obj, T, 9] box tracks (center3, theta_z, wlh3, timestamp, id): renders with "
+                    "the dynamic-object branch (Config.instance_obj=True); needs --track-classes")
+    ap.add_argument("--track-classes", default=None, help="comma-separated nuScenes category per track, e.g. vehicle.car,vehicle.truck")
+    ap.add_argument("--synthetic-tracks", type=int, default=0, help="N seeded boxes placed on rays of the sweep (no dataset in this image)")
     a = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise RuntimeError("render_lidar needs a GPU: the fused path has no CPU fallback")
-    if a.ckpt:
+    dynamic = bool(a.tracks or a.synthetic_tracks)
+    tracks = classes = None
+    if dynamic:
+        from . import objects as nobj
+        if a.tracks:
+            tracks = np.load(a.tracks)
+            classes = (a.track_classes or "").split(",")
+        else:
+            probe = nlidar.synthetic_sweep(width=a.width, seed=a.seed, scale_factor=a.scale_factor)
+            tracks = nobj.synthetic_tracks(probe, a.synthetic_tracks, 20, a.seed, size=(0.02, 0.01, 0.008), depth=(0.02, 0.2))
+            classes = (["vehicle.car", "vehicle.truck", "vehicle.bus.rigid"] * a.synthetic_tracks)[: a.synthetic_tracks]
+    if a.ckpt and dynamic:
+        from .checkpoints import dynamic_model_from_checkpoint
+        base = nconfig.ModelConfig()
+        if a.num_nerf_samples:
+            base.num_nerf_samples = a.num_nerf_samples
+        model, step, ignored = dynamic_model_from_checkpoint(a.ckpt, tracks, classes, base=base, precision=a.precision)
+        print(f"restored step {step} with {len(classes)} tracks; {len(ignored)} keys ignored")
+    elif a.ckpt:
         from .checkpoints import model_from_checkpoint
         base = nconfig.ModelConfig()
         if a.num_nerf_samples:
@@ -99,7 +121,16 @@ def main(argv=None) -> int:
         mc = nconfig.workload(a.workload, a.log2_hashmap)
         if a.num_nerf_samples:
             mc.num_nerf_samples = a.num_nerf_samples
-        model = Model(mc, nweights.synth_state_dict(mc, seed=a.seed, trained_like=True), precision=a.precision)
+        sd = nweights.synth_state_dict(mc, seed=a.seed, trained_like=True)
+        if dynamic:
+            cids = sorted({nobj.query_class(c) for c in classes})
+            lg = a.log2_hashmap or 21
+            sd.update(nweights.synth_object_state_dict({c: nconfig.obj_mlp_config(c, mc.config.latent_size, lg) for c in cids},
+                                                       len(classes), seed=a.seed))
+            mc.config.instance_obj = True
+            model = nobj.DynamicModel(mc, sd, tracks, classes, precision=a.precision, obj_log2_hashmap=lg)
+        else:
+            model = Model(mc, sd, precision=a.precision)
     unet = None
     if a.raydrop_unet:
         from . import raydrop
@@ -113,6 +144,8 @@ def main(argv=None) -> int:
     rot = torch.from_numpy(nlidar.seeded_rotation(a.seed)).float().to(model.device)
     for idx in range(a.sweeps):
         batch = nlidar.synthetic_sweep(width=a.width, seed=a.seed, scale_factor=a.scale_factor, sweep_idx=idx)
+        if dynamic:  # one sweep = one instant (ZI/datasets.py: per-ray timestamps of a sweep are its capture time)
+            batch["timestamp"] = np.full((batch["origins"].shape[0], 1), idx / max(a.sweeps - 1, 1), np.float32)
         t0 = time.time()
         res = render_sweep(model, batch, a.scale_factor)
         torch.cuda.synchronize()

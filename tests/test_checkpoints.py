@@ -184,3 +184,13 @@ def test_render_sweep_points_follow_reference_formula():
     pts, lab = orc.lidar_post(tb, {"depth": res["depth"].cpu(), "semantic": res["semantic"].cpu()}, 1.0 / 250.0)
     np.testing.assert_allclose(res["points"].cpu().numpy(), pts.numpy(), rtol=1e-6, atol=1e-5)
     np.testing.assert_array_equal(res["labels"].cpu().numpy(), lab.numpy())
+
+
+@pytest.mark.gpu
+def test_render_lidar_driver_dynamic_objects(tmp_path):
+    from nerflidar_hip import render_lidar
+    rc = render_lidar.main(["--workload", "REF", "--log2-hashmap", "12", "--width", "64", "--sweeps", "2", "--render-dir", str(tmp_path),
+                            "--synthetic-tracks", "4"])
+    assert rc == 0
+    s0 = np.load(os.path.join(tmp_path, "lidar_replay", "points_semantic_0000.npy"))
+    assert s0.shape == (32 * 64,) and ({13, 14, 15} & set(s0.tolist()))  # some ray ends on an object
