@@ -225,10 +225,18 @@ __global__ void __launch_bounds__(256) nlr_prop_kernel(CastParams cp, GridParams
 // every lane walks all grid levels with its 8*L gathers in flight, and the mean over the multisamples is a 3-step
 // butterfly inside each 8-lane group.  7/8 of the lanes are active for sample_n = 7.
 // =============================================================================================================
+// Sum over the 8 lanes of a group, every lane gets it.  Three DPP adds (VALU) instead of three ds_bpermute round trips:
+// quad_perm [1,0,3,2] and [2,3,0,1] are the xor-1 / xor-2 butterfly steps; after them the four lanes of a quad hold the
+// same bits (a+b == b+a), so row_half_mirror (lane i <- lane 7-i of its 8-lane half row, i.e. some lane of the OTHER
+// quad) delivers exactly what the xor-4 step would: the result is bit-identical to the __shfl_xor butterfly.
+template <int CTRL>
+__device__ __forceinline__ float nlr_dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float nlr_group8_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
+    v += nlr_dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += nlr_dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += nlr_dpp_mov<0x141>(v);  // row_half_mirror
     return v;
 }
 
