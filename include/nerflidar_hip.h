@@ -243,6 +243,29 @@ int nlr_range_project(const double *points, const float *semantic, const float *
                       float *proj_xyz, float *proj_semantic, float *proj_rgb, int32_t *proj_idx, float *proj_mask,
                       void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (6) Training-side operators (with nlr_grid_encode_backward above).
+ *     nlr_composite_backward: gradient of compute_alpha_weights + volumetric_rendering (ZI/render.py:170-252) as
+ *       `loss.backward()` gives it in ZI/train.py:459 - upstream gradients of the per-ray rgb [N,3], depth [N],
+ *       semantic [N,K], intensity [N], acc [N] and of the weights [N,S] themselves (interlevel / distortion losses);
+ *       any may be NULL (= zero).  Outputs: d_density [N,S] (required), d_rgb [3,N,S], d_semantic [K,N,S],
+ *       d_intensity [N,S] (NULL to skip).  semantic / intensity are composited with detached weights
+ *       (render.py:240-252), so their gradients do not reach the density.  Layouts as nlr_composite_level.
+ *     nlr_hash_decay_forward / _backward: ZI/models.py:203-223 for ONE encoder:
+ *       loss = mean over (level, channel) of the level's mean of embeddings^2.  forward writes the per-level sums of
+ *       squares (double [L], device); the caller finishes loss = sum_l level_sumsq[l] / (rows_l * L * C).
+ *       backward ACCUMULATES upstream * dloss/dembeddings into grad_embeddings.  offsets is the HOST table [L+1].
+ * ------------------------------------------------------------------------------------------ */
+int nlr_composite_backward(const float *density, const float *tdist, const float *directions, const float *rgb,
+                           const float *semantic, const float *intensity, uint32_t N, uint32_t S, uint32_t class_num,
+                           int opaque_background, float bg, const float *g_rgb, const float *g_depth,
+                           const float *g_semantic, const float *g_intensity, const float *g_acc, const float *g_weights,
+                           float *d_density, float *d_rgb, float *d_semantic, float *d_intensity, void *stream);
+int nlr_hash_decay_forward(const float *embeddings, const int32_t *offsets_host, uint32_t L, uint32_t C, double *level_sumsq,
+                           void *stream);
+int nlr_hash_decay_backward(const float *embeddings, const int32_t *offsets_host, uint32_t L, uint32_t C, float upstream,
+                            float *grad_embeddings, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) nlr_composite_kernel(CompositeParams P) {
             for (int c = 0; c < 3; ++c)
                 P.o_points[(size_t)ray * 3 + c] = (P.origins[(size_t)ray * 3 + c] + depth * P.dirs[(size_t)ray * 3 + c]) / P.scale_factor;
         }
-        if (P.o_acc && P.extras) P.o_acc[ray] = acc;
+        if (P.o_acc) P.o_acc[ray] = acc;
     }
     if (!P.extras) return;  // uniform across the block
 

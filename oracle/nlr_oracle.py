@@ -395,12 +395,12 @@ def volumetric_rendering(rgbs, weights, tdist, bg_rgbs, t_far, compute_extras, s
     r["rgb"] = (weights[..., None] * rgbs).sum(dim=-2) + bg_w * bg_rgbs
     t_mids = 0.5 * (tdist[..., :-1] + tdist[..., 1:])
     r["depth"] = (weights * t_mids).sum(dim=-1) / acc.clamp_min(EPS)
-    if semantic is not None:
-        r["semantic"] = (weights[..., None] * semantic).sum(dim=-2)
-    if intensity is not None:
+    if semantic is not None:  # render.py:240-246, sem_detach=True: no gradient from the semantic loss into the density
+        r["semantic"] = (weights.clone().detach()[..., None] * semantic).sum(dim=-2)
+    if intensity is not None:  # render.py:248-252
         if intensity.shape != weights.shape:
             intensity = intensity.squeeze(-1)
-        r["intensity"] = (weights * intensity).sum(dim=-1)
+        r["intensity"] = (weights.clone().detach() * intensity).sum(dim=-1)
     if compute_extras:
         r["acc"] = acc
         expectation = lambda x: (weights * x).sum(dim=-1) / acc.clamp_min(EPS)
@@ -609,6 +609,14 @@ def obj_merge(res, objects, sd, batch, tdist, obj_pose):
             mm = m if m.shape == res[key].shape else m[..., None].expand(res[key].shape)
             res[key] = torch.where(mm, tmp, res[key])
     res["obj_mask"] = imap.sum(-1) > 0
+
+
+def hash_decay_loss(embeddings, offsets, mult=1.0):
+    """ZI/models.py:203-223 for one encoder: segment_coo(param ** 2, idx, reduce='mean').mean() with idx = the level of each row
+    (Z/gridencoder/grid.py:138-141), restated with per-level slices."""
+    L = len(offsets) - 1
+    per = [(embeddings[int(offsets[l]):int(offsets[l + 1])] ** 2).mean(dim=0) for l in range(L)]  # [C] per level
+    return mult * torch.stack(per).mean()
 
 
 def lidar_post(batch, rendering, scale_factor):

@@ -375,6 +375,30 @@ def gen_unet():
             save(f"unet_{tag}", x=x, logits=out)
 
 
+def gen_composite_grad():
+    """Row f-3: gradients of the reference's compute_alpha_weights + volumetric_rendering (autograd on the reference's own code)
+    for a loss that touches every differentiable output and the weights themselves."""
+    print("compositing gradient fixtures")
+    for tag, opaque, (N, S, K) in (("opaque", True, (24, 64, 19)), ("transparent", False, (17, 128, 5))):
+        seed = 40 + int(opaque)
+        tdist = torch.sort(rnd(seed, 1, (N, S + 1), 0.05, 2.0), dim=-1)[0]
+        tdist[3, 10] = tdist[3, 9]  # a zero-width interval
+        dens = (rnd(seed, 2, (N, S), 0, 1) ** 4 * 40).requires_grad_(True)
+        dirs = rnd(seed, 3, (N, 3), -1, 1)
+        rgbs = rnd(seed, 4, (N, S, 3)).requires_grad_(True)
+        sem = torch.softmax(rnd(seed, 5, (N, S, K), -2, 2), -1).requires_grad_(True)
+        inten = rnd(seed, 6, (N, S)).requires_grad_(True)
+        cot = {k: rnd(seed, 10 + i, sh, -1, 1) for i, (k, sh) in enumerate(dict(rgb=(N, 3), depth=(N,), semantic=(N, K), intensity=(N,),
+                                                                               acc=(N,), weights=(N, S)).items())}
+        w = rrender.compute_alpha_weights(dens, tdist, dirs, opaque_background=opaque)[0]
+        r = rrender.volumetric_rendering(rgbs, w, tdist, 1.0, torch.full((N, 1), 2.5), True, semantic=sem, intensity=inten)
+        loss = sum((r[k] * cot[k]).sum() for k in ("rgb", "depth", "semantic", "intensity", "acc")) + (w * cot["weights"]).sum()
+        gd, gr, gs, gi = torch.autograd.grad(loss, [dens, rgbs, sem, inten])
+        save(f"fn_composite_grad_{tag}", opaque=np.array(int(opaque)), tdist=tdist, density=dens.detach(), dirs=dirs, rgbs=rgbs.detach(),
+             sem=sem.detach(), intensity=inten.detach(), **{"cot_" + k: v for k, v in cot.items()}, g_density=gd, g_rgbs=gr, g_sem=gs,
+             g_intensity=gi, weights=w.detach(), **{"out_" + k: r[k].detach() for k in ("rgb", "depth", "semantic", "intensity", "acc")})
+
+
 def gen_objects():
     """Row f-1: the reference `Model` with Config.instance_obj=True (latent mode, shipped ObjMLP gin bindings) on a sweep with
     three synthetic tracks; per-function fixtures for get_pose / box_pts and the whole forward."""
@@ -454,4 +478,5 @@ if __name__ == "__main__":
     gen_camera()
     gen_range_image()
     gen_objects()
+    gen_composite_grad()
     print("done")
