@@ -394,7 +394,7 @@ def gen_composite_grad():
         r = rrender.volumetric_rendering(rgbs, w, tdist, 1.0, torch.full((N, 1), 2.5), True, semantic=sem, intensity=inten)
         loss = sum((r[k] * cot[k]).sum() for k in ("rgb", "depth", "semantic", "intensity", "acc")) + (w * cot["weights"]).sum()
         gd, gr, gs, gi = torch.autograd.grad(loss, [dens, rgbs, sem, inten])
-        save(f"fn_composite_grad_{tag}", opaque=np.array(int(opaque)), tdist=tdist, density=dens.detach(), dirs=dirs, rgbs=rgbs.detach(),
+        save(f"grad_composite_{tag}", opaque=np.array(int(opaque)), tdist=tdist, density=dens.detach(), dirs=dirs, rgbs=rgbs.detach(),
              sem=sem.detach(), intensity=inten.detach(), **{"cot_" + k: v for k, v in cot.items()}, g_density=gd, g_rgbs=gr, g_sem=gs,
              g_intensity=gi, weights=w.detach(), **{"out_" + k: r[k].detach() for k in ("rgb", "depth", "semantic", "intensity", "acc")})
 

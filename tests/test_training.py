@@ -1,5 +1,5 @@
 """Scope row f-3 (training-side operators): backward of alpha compositing and the hash-decay regulariser.
-Fixtures `fn_composite_grad_*` are autograd through the REFERENCE's compute_alpha_weights + volumetric_rendering."""
+Fixtures `grad_composite_*` are autograd through the REFERENCE's compute_alpha_weights + volumetric_rendering."""
 import numpy as np
 import pytest
 import torch
@@ -18,7 +18,7 @@ def _loss(r, w, g):
 
 @pytest.mark.parametrize("tag", TAGS)
 def test_oracle_composite_gradients_match_reference(tag):
-    g = golden(f"fn_composite_grad_{tag}")
+    g = golden(f"grad_composite_{tag}")
     dens, rgbs, sem, inten = (T(g[k]).clone().requires_grad_(True) for k in ("density", "rgbs", "sem", "intensity"))
     w = orc.compute_alpha_weights(dens, T(g["tdist"]), T(g["dirs"]), bool(g["opaque"]))
     r = orc.volumetric_rendering(rgbs, w, T(g["tdist"]), 1.0, torch.full((dens.shape[0], 1), 2.5), True, semantic=sem, intensity=inten)
@@ -47,7 +47,7 @@ def test_oracle_hash_decay_is_segment_mean():
 @pytest.mark.parametrize("tag", TAGS)
 def test_composite_forward_backward_match_reference(tag):
     from nerflidar_hip import training
-    g = golden(f"fn_composite_grad_{tag}")
+    g = golden(f"grad_composite_{tag}")
     cu = lambda k: T(g[k]).cuda()
     dens, rgbs, sem, inten = (cu(k).clone().requires_grad_(True) for k in ("density", "rgbs", "sem", "intensity"))
     r = training.volumetric_render(dens, cu("tdist"), cu("dirs"), rgbs, sem, inten, opaque_background=bool(g["opaque"]), bg=1.0)
@@ -65,7 +65,7 @@ def test_composite_forward_backward_match_reference(tag):
 @pytest.mark.gpu
 def test_composite_backward_partial_cotangents_and_errors():
     from nerflidar_hip import training
-    g = golden("fn_composite_grad_opaque")
+    g = golden("grad_composite_opaque")
     cu = lambda k: T(g[k]).cuda()
     dens = cu("density").clone().requires_grad_(True)
     rgbs = cu("rgbs").clone().requires_grad_(True)
