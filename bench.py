@@ -156,7 +156,7 @@ def main():
         # rocprofv3 --pmc run of scripts/pmc_traffic.sh (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if committed.
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_final2_pmc_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_final3_pmc_traffic.json")))
             for k, v in tj.items():
                 if "nlr_mlp_kernel" in k and world == 1 and args.workload == "C2":
                     traffic = v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
@@ -190,7 +190,7 @@ def main():
             "roofline": {"kernel": "nlr_mlp_kernel", "bound": "mfma", "achieved": achieved,
                          "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "bytes per launch from profiles/r01_final2_pmc_traffic.json (separate rocprofv3 --pmc passes)"},
+                         "traffic_note": "bytes per launch from profiles/r01_final3_pmc_traffic.json (separate rocprofv3 --pmc passes)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = host_cores()
