@@ -266,6 +266,17 @@ int nlr_hash_decay_forward(const float *embeddings, const int32_t *offsets_host,
 int nlr_hash_decay_backward(const float *embeddings, const int32_t *offsets_host, uint32_t L, uint32_t C, float upstream,
                             float *grad_embeddings, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (7) Dynamic-object branch: owner of every sample.  winner [N,S] int32 = index of the LAST
+ *     track whose box contains the sample's interval midpoint (ZI/models.py:415,475 let later tracks overwrite
+ *     earlier ones; ZI/obj_utils.py:203-216 inside test), -1 outside every box.  box_params [N, n_obj, 8] =
+ *     (cos theta_z, sin theta_z, t_w_o xyz, scale xyz) per ray and track, with t_w_o = rotate_yaw_z(-center, theta_z)
+ *     and scale = 1 / (wlh / 2 + 1e-9) computed by the caller with the reference's expressions
+ *     (obj_utils.py:5-28,76-113,158-170).
+ * ------------------------------------------------------------------------------------------ */
+int nlr_box_winner(const float *tdist, const float *origins, const float *directions, const float *box_params, uint32_t N,
+                   uint32_t S, uint32_t n_obj, int32_t *winner, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

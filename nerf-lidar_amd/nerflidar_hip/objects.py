@@ -5,7 +5,7 @@ ray's timestamp (`get_pose`); per level, transform the interval midpoints into e
 track's ObjMLP on the samples that fall inside the box and overwrite the static field's per-sample density / rgb /
 semantic there before compositing.  SURVEY 8a routes this branch to "the unfused PyTorch path": here the static field
 still runs on the fused HIP stages (`nlr_resample_level`, `nlr_mlp_level`, `nlr_composite_level`, called level by level
-instead of through `nlr_render_rays`), the object networks are small (L=7 x C=2 grid, 64-wide trunk, 32-wide view MLP)
+instead of through `nlr_render_rays`), `nlr_box_winner` finds the owning track of every sample, the object networks are small (L=7 x C=2 grid, 64-wide trunk, 32-wide view MLP)
 and run as torch ops on the GPU with the hash grid through `nlr_grid_encode_forward`.  No CPU fallback anywhere.
 
 Only latent mode (one ObjMLP per class + one latent code per track, `Config.latent_size > 0`) without symmetry or scene
@@ -98,23 +98,6 @@ def box_pts(pts: torch.Tensor, viewdirs: torch.Tensor, obj_pose: torch.Tensor):
     dirs_o = dirs_o / torch.norm(dirs_o, dim=-1, keepdim=True)
     imap = (pts_o[..., 0].abs() < 1) & (pts_o[..., 1].abs() < 1) & (pts_o[..., 2].abs() < 1)
     return pts_o, dirs_o, imap
-
-
-def rays_near_boxes(origins, dirs, near, far, obj_pose, margin: float = 1e-3) -> torch.Tensor:
-    """Conservative cull: True for rays whose segment [near, far] can have a point inside some box.  The world -> box map of
-    `box_pts` is affine in the point (also with the reference's rotate quirk), so along a ray the box coordinates are
-    o_o + t d_o and the inside test is three slabs in t.  Rays failing it cannot have an inside sample, whatever the level's
-    tdist; the exact per-sample test still decides.  NaNs (0 * inf on an axis-parallel ray) compare False = "keep"."""
-    center, theta, wlh = obj_pose[:, :, :3], obj_pose[:, :, 3], obj_pose[:, :, 4:7]
-    scale = 1 / (wlh / 2 + 1e-9)
-    o_o = scale * (_rotate_yaw_z(origins[:, None, :].expand(-1, obj_pose.shape[1], -1), theta) + _rotate_yaw_z(-center, theta))
-    d_o = scale * _rotate_yaw_z(dirs[:, None, :].expand(-1, obj_pose.shape[1], -1), theta)
-    lim = 1.0 + margin
-    ta, tb = (-lim - o_o) / d_o, (lim - o_o) / d_o
-    tmin = torch.minimum(ta, tb).amax(-1)
-    tmax = torch.maximum(ta, tb).amin(-1)
-    miss = (tmax < tmin) | (tmax < near.reshape(-1, 1) * (1 - margin)) | (tmin > far.reshape(-1, 1) * (1 + margin))
-    return (~miss).any(-1)
 
 
 def _pos_enc(x: torch.Tensor, deg: int) -> torch.Tensor:
@@ -249,8 +232,12 @@ class DynamicModel(Model):
             curr_track = getattr(self, "_track_override", None)
         tracks = self.tracks if curr_track is None else torch.as_tensor(curr_track, device=dev, dtype=f32)
         obj_pose = get_pose(batch["timestamp"].reshape(n, 1).float().to(dev), tracks)
-        cand = rays_near_boxes(origins, dirs, near, far, obj_pose).nonzero().reshape(-1)   # rays that can touch a box
-        o_c, d_c, v_c, pose_c = origins[cand], dirs[cand], viewdirs[cand], obj_pose[cand]
+        # per (ray, track) constants of the world -> box map, with the reference's expressions (obj_utils.py:5-28,158-170)
+        theta = obj_pose[:, :, 3]
+        scale = 1 / (obj_pose[:, :, 4:7] / 2 + 1e-9)
+        t_w_o = _rotate_yaw_z(-obj_pose[:, :, :3], theta)
+        box_params = torch.cat([torch.cos(theta)[..., None], torch.sin(theta)[..., None], t_w_o, scale], dim=-1).contiguous()
+        n_obj = obj_pose.shape[1]
         K = mc.nerf_mlp.class_num if self.config.use_semantic else 0
         new = lambda *shape, dtype=f32: torch.empty(*shape, device=dev, dtype=dtype)
         ws = torch.empty(max(int(L.nlr_workspace_bytes(self._handle, n)), 1 << 20), dtype=torch.uint8, device=dev)
@@ -278,39 +265,45 @@ class DynamicModel(Model):
                                            _lib.ptr(density), _lib.ptr(rgb), _lib.ptr(sem), None, _lib.ptr(ws), ws.numel(), st), "nlr_mlp_level")
                 # ---- dynamic objects: overwrite the samples inside each track's box (models.py:401-477), on the rays that
                 # can reach a box at all (a few % of a sweep); one host sync per level for the per-track counts
-                obj_mask = torch.zeros(n, S, dtype=torch.bool, device=dev)
-                if cand.numel():
-                    td = tdist.index_select(0, cand)
-                    t_mid = 0.5 * (td[:, :-1] + td[:, 1:])
-                    pts_w = t_mid[..., None] * d_c[:, None, :] + o_c[:, None, :]
-                    pts_o, dirs_o, imap = box_pts(pts_w, v_c, pose_c)
-                    # The reference loops over tracks and lets later tracks overwrite earlier ones where boxes overlap
-                    # (models.py:415,475): only the LAST intersecting track of a sample survives, so only that one is
-                    # evaluated, all tracks of one class in a single ObjMLP call with a latent code per point.
-                    winner = (imap * self._track_rank).amax(-1) - 1                       # [Nc, S], -1 = outside every box
-                    sel = (winner >= 0).nonzero()                                          # host sync 1: [P, 2]
-                    if sel.shape[0]:
-                        ci, si = sel[:, 0], sel[:, 1]
-                        tr = winner[ci, si]
-                        order = torch.sort(self._class_rank[tr], stable=True)[1]
-                        ci, si, tr = ci[order], si[order], tr[order]
-                        per_class = torch.bincount(self._class_rank[tr], minlength=len(self._class_list)).tolist()   # host sync 2
-                        idx = cand[ci] * S + si
-                        p_all, d_all = pts_o[ci, si, tr], dirs_o[ci, si, tr]
-                        lat_all = self._latent_table[tr] if self._latent_table is not None else None
-                        lo = 0
-                        for rank, cnt in enumerate(per_class):
-                            if cnt == 0:
-                                continue
-                            sl = slice(lo, lo + cnt)
-                            lo += cnt
-                            o = self.obj_mlps[self._class_list[rank]].forward(p_all[sl], d_all[sl], None if lat_all is None else lat_all[sl])
-                            density.view(-1)[idx[sl]] = o["density"]
-                            if last:
-                                rgb.view(3, -1)[:, idx[sl]] = o["rgb"].t()
-                                if sem is not None:
-                                    sem.view(K, -1)[:, idx[sl]] = o["semantic"].t()
-                        obj_mask.view(-1)[idx] = True
+                # owner of every sample (nlr_box_winner: the last track whose box holds the interval midpoint; the reference's
+                # track loop overwrites earlier tracks, models.py:415,475), then only the owned samples - 0.1-2 % of a sweep -
+                # are gathered, all tracks of one class through one ObjMLP call with a latent code per point
+                winner = new(n, S, dtype=torch.int32)
+                _lib.check(L.nlr_box_winner(_lib.ptr(tdist), _lib.ptr(origins), _lib.ptr(dirs), _lib.ptr(box_params), n, S, n_obj,
+                                            _lib.ptr(winner), st), "nlr_box_winner")
+                obj_mask = winner >= 0
+                sel = obj_mask.nonzero()                                                   # host sync 1: [P, 2]
+                if sel.shape[0]:
+                    ri, si = sel[:, 0], sel[:, 1]
+                    tr = winner[ri, si].long()
+                    order = torch.sort(self._class_rank[tr], stable=True)[1]
+                    ri, si, tr = ri[order], si[order], tr[order]
+                    per_class = torch.bincount(self._class_rank[tr], minlength=len(self._class_list)).tolist()   # host sync 2
+                    # box coordinates of the owned samples, by the expressions of obj_utils.world2object (:158-176)
+                    bp = box_params[ri, tr]
+                    t_mid = 0.5 * (tdist[ri, si] + tdist[ri, si + 1])
+                    pw = t_mid[:, None] * dirs[ri] + origins[ri]
+                    cs, sn = bp[:, 0], bp[:, 1]
+                    rx = cs * pw[:, 0] - sn * pw[:, 1]
+                    p_all = bp[:, 5:8] * (torch.stack([rx, sn * rx + cs * pw[:, 1], pw[:, 2]], dim=-1) + bp[:, 2:5])
+                    vd = viewdirs[ri]
+                    vx = cs * vd[:, 0] - sn * vd[:, 1]
+                    d_all = bp[:, 5:8] * torch.stack([vx, sn * vx + cs * vd[:, 1], vd[:, 2]], dim=-1)
+                    d_all = d_all / torch.norm(d_all, dim=-1, keepdim=True)
+                    lat_all = self._latent_table[tr] if self._latent_table is not None else None
+                    idx = ri * S + si
+                    lo = 0
+                    for rank, cnt in enumerate(per_class):
+                        if cnt == 0:
+                            continue
+                        sl = slice(lo, lo + cnt)
+                        lo += cnt
+                        o = self.obj_mlps[self._class_list[rank]].forward(p_all[sl], d_all[sl], None if lat_all is None else lat_all[sl])
+                        density.view(-1)[idx[sl]] = o["density"]
+                        if last:
+                            rgb.view(3, -1)[:, idx[sl]] = o["rgb"].t()
+                            if sem is not None:
+                                sem.view(K, -1)[:, idx[sl]] = o["semantic"].t()
                 weights, depth_l = new(n, S), new(n)
                 out = _lib.NlrOut()
                 if last:
