@@ -261,6 +261,11 @@ int nlr_composite_backward(const float *density, const float *tdist, const float
                            int opaque_background, float bg, const float *g_rgb, const float *g_depth,
                            const float *g_semantic, const float *g_intensity, const float *g_acc, const float *g_weights,
                            float *d_density, float *d_rgb, float *d_semantic, float *d_intensity, void *stream);
+/* rows a-5 + a-6 as an operator: cast_rays + contract + /bound (ZI/render.py:129-168, ZI/coord.py:51-63, ZI/models.py:965-973).
+ * means [N,S,n,3] (in [-1,1], what GridEncoder(bound=1) takes), stds [N,S,n].  No gradient: tdist is detached in training
+ * (Model.stop_level_grad) and rays are data. */
+int nlr_cast_contract(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n, uint32_t sample_m,
+                      float std_scale, const float *rand_deg, float *means, float *stds, void *stream);
 int nlr_hash_decay_forward(const float *embeddings, const int32_t *offsets_host, uint32_t L, uint32_t C, double *level_sumsq,
                            void *stream);
 int nlr_hash_decay_backward(const float *embeddings, const int32_t *offsets_host, uint32_t L, uint32_t C, float upstream,

@@ -19,7 +19,8 @@ struct Gauss {  // one contracted multisample, mapped to the unit cube
 };
 
 __device__ __forceinline__ Gauss nlr_cast_one(const CastParams &cp, uint32_t ray, uint32_t k, uint32_t j, float t0, float t1,
-                                              const float *o, const float *d, const float *bx, const float *by, float radius) {
+                                              const float *o, const float *d, const float *bx, const float *by, float radius,
+                                              float *raw = nullptr) {
     // render.py:147-156
     const float t = t0 + ((t1 - t0) * ((float)j + 0.5f)) / (float)cp.n;
     float cd = cp.cosd[j], sd = cp.sind[j];
@@ -55,6 +56,11 @@ __device__ __forceinline__ Gauss nlr_cast_one(const CastParams &cp, uint32_t ray
     g.x1 = (m[1] / 2.0f + 1.0f) / 2.0f;
     g.x2 = (m[2] / 2.0f + 1.0f) / 2.0f;
     g.zs = zs / 2.0f;
+    if (raw) {  // means / bound as GridEncoder(bound=1) takes them (models.py:969-973)
+        raw[0] = m[0] / 2.0f;
+        raw[1] = m[1] / 2.0f;
+        raw[2] = m[2] / 2.0f;
+    }
     return g;
 }
 
@@ -346,6 +352,49 @@ __global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParam
         const float x = raw + mp.density_bias;
         density[m] = x > 20.0f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20), models.py:1116
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rows a-5 / a-6 alone (training path, nerflidar_hip/training.py): the contracted multisample means / bound and stds / bound
+// that MLP.predict_density hands to the GridEncoder (ZI/models.py:965-973), one thread per (sample, multisample).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nlr_cast_contract_kernel(CastParams cp, float *__restrict__ means, float *__restrict__ stds) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t M = (size_t)cp.N * cp.S;
+    if (t >= M * cp.n) return;
+    const uint32_t m = (uint32_t)(t / cp.n), j = (uint32_t)(t - (size_t)m * cp.n);
+    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    float o[3], d[3], bx[3], by[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = cp.origins[(size_t)ray * 3 + c];
+        d[c] = cp.directions[(size_t)ray * 3 + c];
+        bx[c] = cp.base_x[(size_t)ray * 3 + c];
+        by[c] = cp.base_y[(size_t)ray * 3 + c];
+    }
+    const float t0 = cp.tdist[(size_t)ray * (cp.S + 1) + k], t1 = cp.tdist[(size_t)ray * (cp.S + 1) + k + 1];
+    float raw[3];
+    const Gauss g = nlr_cast_one(cp, ray, k, j, t0, t1, o, d, bx, by, cp.radii[ray], raw);
+    means[t * 3 + 0] = raw[0];
+    means[t * 3 + 1] = raw[1];
+    means[t * 3 + 2] = raw[2];
+    stds[t] = g.zs;
+}
+
+int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist, const float *rand_deg, uint32_t N,
+                         uint32_t S, uint32_t n, uint32_t mloops, float std_scale);
+
+extern "C" int nlr_cast_contract(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n,
+                                 uint32_t sample_m, float std_scale, const float *rand_deg, float *means, float *stds, void *stream) {
+    NLR_CHECK_ARG(tdist && means && stds, "cast_contract: NULL tensor");
+    if (N == 0 || S == 0) return NLR_OK;
+    CastParams cp;
+    int rc = nlr_fill_cast_params(&cp, rays, tdist, rand_deg, N, S, sample_n, sample_m, std_scale);
+    if (rc) return rc;
+    const size_t total = (size_t)N * S * sample_n;
+    hipLaunchKernelGGL(nlr_cast_contract_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cp, means, stds);
+    NLR_LAUNCH_CHECK("nlr_cast_contract_kernel");
+    return NLR_OK;
 }
 
 // ---- host side ---------------------------------------------------------------------------------

@@ -72,7 +72,7 @@ EXPORTS = ["nlr_last_error", "nlr_version", "nlr_grid_encode_forward", "nlr_grid
            "nlr_sample_u", "nlr_model_create", "nlr_model_destroy", "nlr_model_set_table", "nlr_workspace_bytes",
            "nlr_render_rays", "nlr_kernel_names", "nlr_resample_level", "nlr_mlp_level", "nlr_composite_level",
            "nlr_profile_begin", "nlr_profile_end", "nlr_range_workspace_bytes", "nlr_range_project",
-           "nlr_composite_backward", "nlr_hash_decay_forward", "nlr_hash_decay_backward", "nlr_box_winner"]
+           "nlr_composite_backward", "nlr_hash_decay_forward", "nlr_hash_decay_backward", "nlr_box_winner", "nlr_cast_contract"]
 NLR_K_COUNT = 6
 
 
@@ -119,6 +119,8 @@ def lib():
                                              C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
         L.nlr_hash_decay_forward.argtypes = [c_fp, c_fp, C.c_uint32, C.c_uint32, c_fp, c_fp]
         L.nlr_hash_decay_backward.argtypes = [c_fp, c_fp, C.c_uint32, C.c_uint32, C.c_float, c_fp, c_fp]
+        L.nlr_cast_contract.argtypes = [C.POINTER(NlrRays), c_fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, c_fp, c_fp, c_fp,
+                                        c_fp]
         L.nlr_box_winner.argtypes = [c_fp, c_fp, c_fp, c_fp, C.c_uint32, C.c_uint32, C.c_uint32, c_fp, c_fp]
         L.nlr_profile_begin.argtypes = [c_fp]
         L.nlr_profile_end.argtypes = [c_fp, c_fp, c_fp, c_fp]

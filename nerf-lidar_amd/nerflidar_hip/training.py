@@ -124,3 +124,110 @@ def hash_decay_loss(encoders, mult: float = 1.0) -> torch.Tensor:
         l = _HashDecay.apply(enc.embeddings, enc._offsets_host)
         total = l if total is None else total + l
     return mult * total
+
+
+# ---- a trainable NerfMLP level: fused cast/contract + HIP grid op (fwd/bwd) + torch Linear stack + HIP compositing (fwd/bwd) ----------
+def cast_contract(batch: Dict[str, torch.Tensor], tdist: torch.Tensor, sample_n: int = 7, sample_m: int = 3, std_scale: float = 0.35):
+    """Rows a-5 + a-6 (`nlr_cast_contract`): multisample means / bound [N,S,n,3] and stds / bound [N,S,n] of the intervals of
+    `tdist`, as MLP.predict_density feeds them to the encoder (ZI/models.py:965-973).  Carries no gradient (tdist is detached in
+    training, Model.stop_level_grad)."""
+    from .models import _RAY_KEYS
+    n, S = tdist.shape[0], tdist.shape[1] - 1
+    dev = tdist.device
+    if not tdist.is_cuda:
+        raise RuntimeError("cast_contract: tdist must be a CUDA tensor (no CPU fallback)")
+    rays, keep = _lib.NlrRays(), []
+    for k in _RAY_KEYS:
+        t = batch[k].reshape(n, -1).contiguous().float()
+        keep.append(t)
+        setattr(rays, k, t.data_ptr())
+    td = tdist.detach().contiguous().float()
+    means = torch.empty(n, S, sample_n, 3, device=dev)
+    stds = torch.empty(n, S, sample_n, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().nlr_cast_contract(C.byref(rays), _lib.ptr(td), n, S, sample_n, sample_m, float(std_scale), None, _lib.ptr(means),
+                                          _lib.ptr(stds), _lib.current_stream())
+    _lib.check(rc, "nlr_cast_contract")
+    return means, stds
+
+
+def encode_features(encoder, means: torch.Tensor, stds: torch.Tensor, re_weights: bool = True) -> torch.Tensor:
+    """ZI/models.py:974-979: grid features of every multisample, erf down-weighting by footprint, mean over the multisamples.
+    Differentiable with respect to `encoder.embeddings` through the HIP grid operator's backward."""
+    L = encoder.num_levels
+    f = encoder(means.reshape(-1, 3), bound=1).reshape(means.shape[:-1] + (L, -1))          # [N,S,n,L,C]
+    if re_weights:
+        gs = encoder.grid_sizes.to(means.device).float()
+        w = torch.erf(1 / torch.clamp(torch.sqrt(8 * stds[..., None] ** 2 * gs ** 2), min=1e-10))
+        f = (f * w[..., None]).mean(dim=-3)
+    else:
+        f = f.mean(dim=-3) if f.dim() > 3 else f
+    return f.flatten(-2, -1)
+
+
+class TrainableNerfLevel(torch.nn.Module):
+    """The final (NerfMLP) level as a trainable module with the reference's parameter names (`encoder.embeddings`,
+    `density_layer.0.weight`, `lin_second_stage_3.bias`, `sem_layer.2.weight`, ...; ZI/models.py:847-961), so that
+    `load_state_dict({k[len('nerf_mlp.'):]: v ...})` takes a reference checkpoint and the trained weights go back into
+    `nerflidar_hip.models.Model` for fused inference.  forward = MLP.forward (models.py:1036-1265, inference subset:
+    disable_density_normals, no GLO) on the intervals of `tdist`; `render` adds the compositing."""
+
+    def __init__(self, cfg, table_std: float = 1e-4):
+        super().__init__()
+        from .gridencoder import GridEncoder
+        nn = torch.nn
+        self.cfg = cfg
+        self.encoder = GridEncoder(input_dim=3, num_levels=cfg.grid_num_levels, level_dim=cfg.grid_level_dim,
+                                   base_resolution=cfg.grid_base_resolution, desired_resolution=cfg.grid_disired_resolution,
+                                   log2_hashmap_size=cfg.grid_log2_hashmap_size, gridtype="hash", align_corners=False)
+        feat = cfg.grid_num_levels * cfg.grid_level_dim
+        self.density_layer = nn.Sequential(nn.Linear(feat, 64), nn.ReLU(), nn.Linear(64, cfg.bottleneck_width))
+        in_rgb = cfg.bottleneck_width + cfg.dim_dir_enc
+        last = in_rgb
+        for i in range(cfg.net_depth_viewdirs):
+            lin = nn.Linear(last, cfg.net_width_viewdirs)
+            nn.init.kaiming_uniform_(lin.weight)
+            self.add_module(f"lin_second_stage_{i}", lin)
+            last = cfg.net_width_viewdirs + (in_rgb if i == cfg.skip_layer_dir else 0)
+        self.rgb_layer = nn.Linear(last, cfg.num_rgb_channels)
+        if cfg.use_semantic and not cfg.no_sem_layer:
+            self.sem_layer = nn.Sequential(nn.Linear(cfg.bottleneck_width, 64), nn.ReLU(), nn.Linear(64, cfg.class_num))
+        if cfg.use_intensity:
+            self.intensity_layer = nn.Sequential(nn.Linear(cfg.bottleneck_width, 64), nn.ReLU(), nn.Linear(64, 1))
+
+    def load_reference(self, state_dict, prefix: str = "nerf_mlp."):
+        sd = {k[len(prefix):]: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v)))
+              for k, v in state_dict.items() if k.startswith(prefix) and not k.endswith(("encoder.offsets", "encoder.grid_sizes", "encoder.idx"))}
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        bad = [m for m in missing if not m.startswith("encoder.") or m == "encoder.embeddings"]
+        if bad or unexpected:
+            raise KeyError(f"state_dict mismatch: missing {bad}, unexpected {list(unexpected)}")
+        return self
+
+    def forward(self, batch: Dict[str, torch.Tensor], tdist: torch.Tensor, sample_n: int = 7, sample_m: int = 3) -> Dict[str, torch.Tensor]:
+        from .objects import _pos_enc
+        F = torch.nn.functional
+        cfg = self.cfg
+        means, stds = cast_contract(batch, tdist, sample_n, sample_m)
+        x = self.density_layer(encode_features(self.encoder, means, stds, cfg.re_weights))
+        out = {"density": F.softplus(x[..., 0] + cfg.density_bias)}
+        if cfg.use_semantic:
+            out["semantic"] = torch.softmax(x[..., 1:1 + cfg.class_num] if cfg.no_sem_layer else self.sem_layer(x), -1)
+        if cfg.use_intensity:
+            out["intensity"] = self.intensity_layer(x)[..., 0]
+        enc = _pos_enc(batch["viewdirs"].reshape(x.shape[0], 3).float(), cfg.deg_view)
+        h = torch.cat([x, enc[:, None, :].expand(-1, x.shape[1], -1)], dim=-1)
+        inputs = h
+        for i in range(cfg.net_depth_viewdirs):
+            h = F.relu(getattr(self, f"lin_second_stage_{i}")(h))
+            if i == cfg.skip_layer_dir:
+                h = torch.cat([h, inputs], dim=-1)
+        rgb = torch.sigmoid(cfg.rgb_premultiplier * self.rgb_layer(h) + cfg.rgb_bias)
+        out["rgb"] = rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
+        return out
+
+    def render(self, batch, tdist, opaque_background: bool = True, bg: float = 1.0, **kw):
+        o = self.forward(batch, tdist, **kw)
+        r = volumetric_render(o["density"], tdist, batch["directions"].reshape(tdist.shape[0], 3), o["rgb"], o.get("semantic"),
+                              o.get("intensity"), opaque_background, bg)
+        return r, o

@@ -129,5 +129,77 @@ def test_training_slice_decreases_loss():
         opt.zero_grad()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < 0.2 * losses[0], losses[::6]
+
+
+@pytest.mark.gpu
+def test_trainable_level_matches_oracle_forward_and_gradients():
+    """cast/contract op + HIP grid fwd/bwd + torch Linear stack + HIP compositing fwd/bwd against the oracle (torch CPU autograd
+    for the Linear parameters, the C grid oracle's backward for the table)."""
+    from nerflidar_hip import config as nconfig, lidar as nlidar, training, weights as nweights
+    mc = nconfig.workload("C2", 12)
+    sd = nweights.synth_state_dict(mc, seed=5, trained_like=True)
+    b = nlidar.synthetic_sweep(width=4, seed=5, beams=nlidar.LIDAR_ANGLES[::8])
+    N, S = b["origins"].shape[0], 32
+    rng = np.random.default_rng(0)
+    tdist = np.sort(rng.uniform(0.01, 1.5, (N, S + 1)).astype(np.float32), axis=-1)
+    cot = {k: rng.normal(size=sh).astype(np.float32) for k, sh in dict(rgb=(N, 3), depth=(N,), semantic=(N, 19), intensity=(N,)).items()}
+    lvl = training.TrainableNerfLevel(mc.nerf_mlp).load_reference(sd).cuda()
+    batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    store, orig = {}, training.encode_features
+
+    def keep_grad(*a, **k):
+        f = orig(*a, **k)
+        f.retain_grad()
+        store["f"] = f
+        return f
+    training.encode_features = keep_grad
+    try:
+        r, o = lvl.render(batch, torch.from_numpy(tdist).cuda())
+        loss = sum((r[k] * torch.from_numpy(cot[k]).cuda()).sum() for k in cot)
+        loss.backward()
+    finally:
+        training.encode_features = orig
+    # oracle: same level with torch CPU autograd on the Linear parameters
+    enc = orc.make_encoders(sd, mc)["nerf_mlp"]
+    sd_t = {k: v.clone().requires_grad_(True) for k, v in orc.to_torch_sd(sd).items() if k.startswith("nerf_mlp.")}
+    bt = {k: torch.from_numpy(v) for k, v in b.items()}
+    means, stds = orc.cast_rays(torch.from_numpy(tdist), bt["origins"], bt["directions"], bt["radii"], bt["base_x"], bt["base_y"], n=7, m=3,
+                                std_scale=0.35)
+    res = orc.mlp_forward(sd_t, "nerf_mlp", mc.nerf_mlp, enc, means, stds, bt["viewdirs"])
+    w = orc.compute_alpha_weights(res["density"], torch.from_numpy(tdist), bt["directions"], True)
+    ro = orc.volumetric_rendering(res["rgb"], w, torch.from_numpy(tdist), 1.0, bt["far"], False, semantic=res["semantic"], intensity=res["intensity"])
+    lo = sum((ro[k] * torch.from_numpy(cot[k])).sum() for k in cot)
+    lo.backward()
+    for k in ("rgb", "depth", "semantic", "intensity"):
+        np.testing.assert_allclose(r[k].detach().cpu().numpy(), ro[k].detach().numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
+    for name, p in lvl.named_parameters():
+        if name == "encoder.embeddings":
+            continue
+        want = sd_t["nerf_mlp." + name].grad.numpy()
+        got = p.grad.cpu().numpy()
+        scale = max(np.abs(want).max(), 1e-6)
+        assert np.abs(got - want).max() <= 5e-3 * scale, (name, np.abs(got - want).max(), scale)
+    g_tab = lvl.encoder.embeddings.grad.cpu().numpy()
+    assert np.isfinite(g_tab).all() and np.abs(g_tab).max() > 0
+    # table gradient: dL/dfeatures pushed through (mean over 7, erf weights) and the C oracle of kernel_grid_backward
+    cfg = mc.nerf_mlp
+    L, Cc = cfg.grid_num_levels, cfg.grid_level_dim
+    m_h, s_h = training.cast_contract(batch, torch.from_numpy(tdist).cuda())
+    gs = torch.from_numpy(sd["nerf_mlp.encoder.grid_sizes"]).float()
+    w = torch.erf(1 / torch.clamp(torch.sqrt(8 * s_h.cpu()[..., None] ** 2 * gs ** 2), min=1e-10))          # [N,S,7,L]
+    g_raw = store["f"].grad.cpu().reshape(N, S, 1, L, Cc) * w[..., None] / 7.0                                 # [N,S,7,L,C]
+    gl = g_raw.reshape(-1, L, Cc).permute(1, 0, 2).contiguous().numpy()
+    x01 = ((m_h.cpu().reshape(-1, 3) + 1) / 2).numpy()
+    from nerflidar_hip.weights import grid_layout
+    offsets, _, pls = grid_layout(cfg)
+    want_tab, _ = orc.grid_backward_c(gl, x01, offsets, g_tab.shape[0], Cc, float(np.log2(pls)), cfg.grid_base_resolution)
+    scale = np.abs(want_tab).max()
+    assert np.abs(g_tab - want_tab).max() <= 2e-3 * scale, (np.abs(g_tab - want_tab).max(), scale)
+    # means/stds operator against the oracle's cast_rays + contraction
+    m_hip, s_hip = training.cast_contract(batch, torch.from_numpy(tdist).cuda())
+    cm, cs = orc.contract_mean_std(means.reshape(-1, 3), stds.reshape(-1))
+    cm, cs = cm.reshape(means.shape), cs.reshape(stds.shape)
+    np.testing.assert_allclose(m_hip.cpu().numpy(), (cm / 2).numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(s_hip.cpu().numpy(), (cs / 2).numpy(), rtol=2e-5, atol=1e-9)
