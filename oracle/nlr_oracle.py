@@ -489,25 +489,18 @@ def model_forward(sd_np, mc, batch: Dict[str, torch.Tensor], train_frac=1.0, com
 # f-1  dynamic-object branch (ZI/models.py:93-177,306-315,401-477; ZI/obj_utils.py:5-28,76-113,116-234,431-475)
 # --------------------------------------------------------------------------------------------
 def obj_get_pose(time, tracks):
-    """obj_utils.py:431-475.  time [N,1]; tracks [N_obj, T, 9] = (center3, theta_z, wlh3, timestamp, track_id) -> [N, N_obj, 9]:
-    the two recorded poses closest in time, blended with weight |t - t2| / (|t1 - t2| + 1e-9) clamped to [0,1] on the closest."""
-    time_diff = torch.abs(time[..., None] - tracks[:, :, -2].unsqueeze(0))
-    _, indices = torch.sort(time_diff, dim=-1)
-    closest = indices[..., :2]
-    n, n_obj, n_info = time.shape[0], tracks.shape[0], tracks.shape[-1]
-    time_expand = time.unsqueeze(-1).expand(-1, n_obj, n_info)
-    t_expand = tracks[:, :, -2].unsqueeze(0).expand(n, -1, -1)
-    tracks_expand = tracks.unsqueeze(0).expand(n, -1, -1, -1)
-    ci = closest.unsqueeze(-1).expand(-1, -1, -1, n_info)
-    t1 = torch.gather(t_expand, dim=-1, index=ci[..., 0, :]).squeeze(-1)
-    t2 = torch.gather(t_expand, dim=-1, index=ci[..., 1, :]).squeeze(-1)
-    # (sic) t_expand has T columns and the index n_info columns: the gather yields [N, N_obj, n_info] copies of the two times
-    total = torch.abs(t1 - t2) + 1e-9
-    w1 = (torch.abs(time_expand - t2) / total).clamp(0, 1)
-    w2 = 1 - w1
-    info1 = torch.gather(tracks_expand, dim=-2, index=ci[..., 0, :].unsqueeze(-2)).squeeze(dim=-2)
-    info2 = torch.gather(tracks_expand, dim=-2, index=ci[..., 1, :].unsqueeze(-2)).squeeze(dim=-2)
-    return w1 * info1 + w2 * info2
+    """obj_utils.py:431-475.  time [N,1]; tracks [N_obj, T, 9] = (center3, theta_z, wlh3, timestamp, track_id) -> [N, N_obj, 9].
+    Per ray and track: the two recorded poses nearest in time (a = nearest, b = second nearest), blended as
+    w a + (1 - w) b with w = clamp(|t - t_b| / (|t_a - t_b| + 1e-9), 0, 1); every one of the 9 columns is blended, the
+    timestamp and the track id included."""
+    rec_t = tracks[:, :, 7]                                            # [N_obj, T]
+    order = torch.argsort((time[:, :, None] - rec_t[None]).abs(), dim=-1, stable=False)
+    ia, ib = order[..., 0], order[..., 1]                              # [N, N_obj]
+    obj = torch.arange(tracks.shape[0])[None, :].expand_as(ia)
+    pa, pb = tracks[obj, ia], tracks[obj, ib]                          # [N, N_obj, 9]
+    ta, tb = pa[..., 7:8], pb[..., 7:8]
+    w = ((time[:, :, None] - tb).abs() / ((ta - tb).abs() + 1e-9)).clamp(0, 1)
+    return w * pa + (1 - w) * pb
 
 
 def obj_rotate_yaw_z(p, yaw):
