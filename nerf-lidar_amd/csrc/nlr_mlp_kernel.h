@@ -81,20 +81,24 @@ struct Tape {
         nxt = (nxt + 1 == total) ? 0 : nxt + 1;
         const uint32_t v = (uint32_t)lane * 16u;
         uint32_t keep;
+        // The instruction offset advances the global AND the LDS address (LDS address = M0 + offset + 16 * lane), so four
+        // pieces share one M0 value and one SGPR base: 2 x (M0 write + 4 DMA instructions) instead of 8 x (M0 write,
+        // 64-bit scalar add, DMA) - the scalar bookkeeping, not the DMA itself, was most of a piece's issue cost.
         asm volatile(
             "s_mov_b32 %[k], m0\n\t"
-            "s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g0]\n\t"
-            "s_add_u32 m0, %[l], 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g1]\n\t"
-            "s_add_u32 m0, %[l], 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g2]\n\t"
-            "s_add_u32 m0, %[l], 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g3]\n\t"
-            "s_add_u32 m0, %[l], 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g4]\n\t"
-            "s_add_u32 m0, %[l], 0x1400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g5]\n\t"
-            "s_add_u32 m0, %[l], 0x1800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g6]\n\t"
-            "s_add_u32 m0, %[l], 0x1c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g7]\n\t"
+            "s_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[v], %[g0]\n\t"
+            "global_load_lds_dwordx4 %[v], %[g0] offset:1024\n\t"
+            "global_load_lds_dwordx4 %[v], %[g0] offset:2048\n\t"
+            "global_load_lds_dwordx4 %[v], %[g0] offset:3072\n\t"
+            "s_add_u32 m0, %[l], 0x1000\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[v], %[g4]\n\t"
+            "global_load_lds_dwordx4 %[v], %[g4] offset:1024\n\t"
+            "global_load_lds_dwordx4 %[v], %[g4] offset:2048\n\t"
+            "global_load_lds_dwordx4 %[v], %[g4] offset:3072\n\t"
             "s_mov_b32 m0, %[k]"
             : [k] "=&s"(keep)
-            : [v] "v"(v), [l] "s"(l), [g0] "s"(g), [g1] "s"(g + 1024), [g2] "s"(g + 2048), [g3] "s"(g + 3072), [g4] "s"(g + 4096),
-              [g5] "s"(g + 5120), [g6] "s"(g + 6144), [g7] "s"(g + 7168)
+            : [v] "v"(v), [l] "s"(l), [g0] "s"(g), [g4] "s"(g + 4096)
             : "memory", "scc");
     }
     // Workgroup hand-shake without s_barrier.  A barrier per chunk cost 16 % of the kernel (stamps): the four
