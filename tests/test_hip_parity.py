@@ -450,3 +450,20 @@ def test_error_behaviour():
         Model(mc2, nweights.synth_state_dict(mc2, seed=0), device=DEV)
     rc = _lib.lib().nlr_render_rays(model._handle, None, 4, None, None, None, 0, None)
     assert rc == -1 and b"NULL" in _lib.lib().nlr_last_error()
+
+
+@pytest.mark.parametrize("wl", ["C2", "REF"])
+def test_ragged_ray_counts_are_consistent(wl):
+    """Rays are independent: any prefix of a batch must render bit-identically to the same rays inside the full batch, whatever
+    the ray count does to tile / workgroup / wave boundaries (1 ray, non-multiples of 4, 32, 128; persistent-workgroup tails)."""
+    mc = nconfig.workload(wl, 12)
+    sd = nweights.synth_state_dict(mc, seed=11, trained_like=True)
+    from nerflidar_hip.models import Model
+    model = Model(mc, sd, device=DEV, precision=_lib.PREC_FAST)
+    b = nlidar.synthetic_sweep(width=40, seed=11)   # 1280 rays
+    full = {k: cu(v) for k, v in b.items()}
+    rf, _ = model.render_rays(full, scale_factor=0.004)
+    for n in (1, 3, 127, 129, 1000, 1279):
+        rn, _ = model.render_rays({k: v[:n].contiguous() for k, v in full.items()}, scale_factor=0.004)
+        for k in ("depth", "rgb", "semantic", "labels", "points", "acc", "distance_median"):
+            assert torch.equal(rn[k], rf[k][:n]), (wl, n, k)
