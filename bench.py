@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table-dtype", choices=["f32", "f16"], default="f32", help="hash-table storage; f32 is the benchmark "
                     "configuration, f16 is what the reference uses under autocast (Z/gridencoder/grid.py:43-44)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise RCCL and run the collectives also with one rank")
     ap.add_argument("--chunk", type=int, default=0, help="rays per nlr_render_rays call (0 = the whole sector at once; the "
                     "reference's driver uses Config.render_chunk_size = 16384, ZI/configs.py)")
     args = ap.parse_args()
@@ -94,9 +95,13 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:  # rehearsal without a launcher
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     mc = nconfig.workload(args.workload, args.log2_hashmap)
     sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
@@ -117,10 +122,10 @@ def main():
         else:
             r, _ = model.render_rays(batch, compute_extras=True, scale_factor=sf)
         tile = sharding.pack_tile(r, H_BEAMS, wp)
-        return sharding.gather_tiles(tile, width)
+        return sharding.gather_tiles(tile, width, force=args.force_dist)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -137,7 +142,7 @@ def main():
     ms = (C.c_float * _lib.NLR_K_COUNT)()
     cnt = (C.c_uint32 * _lib.NLR_K_COUNT)()
     _lib.check(L.nlr_profile_end(model._handle, _lib.current_stream(), ms, cnt), "nlr_profile_end")
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -196,7 +201,7 @@ def main():
             threads = host_cores()
             out["cpu_baseline"] = cpu_baseline(mc, sd, sec, args.cpu_rays, threads)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

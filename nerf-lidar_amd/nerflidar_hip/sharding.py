@@ -55,10 +55,11 @@ def render_sweep_sharded(render_fn: Callable[[Dict[str, torch.Tensor]], Dict[str
     return gather_tiles(tile, width, group)
 
 
-def gather_tiles(tile: torch.Tensor, width: int, group=None) -> torch.Tensor:
-    """ONE all-gather of the packed [H, W/P, C] tile -> [H, W, C] (pad columns stripped)."""
+def gather_tiles(tile: torch.Tensor, width: int, group=None, force: bool = False) -> torch.Tensor:
+    """ONE all-gather of the packed [H, W/P, C] tile -> [H, W, C] (pad columns stripped).  `force` runs the collective
+    even with a single rank (rehearsal of the RCCL path on a one-GPU box)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return tile[:, :width]
     h, wp, c = tile.shape
     out = torch.empty(world * h, wp, c, device=tile.device, dtype=tile.dtype)  # rank-major concatenation
