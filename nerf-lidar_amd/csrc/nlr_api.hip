@@ -456,7 +456,9 @@ extern "C" size_t nlr_workspace_bytes(const NlrModel *m, uint32_t N) {
 // Run encode + MLP of one NerfMLP level (or the fused proposal kernel) for given tdist.
 static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays *rays, const float *tdist, uint32_t N,
                          uint32_t n, uint32_t mloops, const float *rand_deg, float *feat, float *raybias, float *density,
-                         float *rgb, float *sem, float *inten, float *prop_feat, hipStream_t st) {
+                         float *rgb, float *sem, float *inten, float *prop_feat, hipStream_t st, bool internal_feat = false) {
+    // features in the workspace (never seen by the caller) take the piece-major layout when the fast kernels apply
+    const int piece_major = (internal_feat && !lv.is_prop && lv.gp.C == 4 && n <= 8 && lv.F % 4 == 0) ? 1 : 0;
     CastParams cp;
     int rc = nlr_fill_cast_params(&cp, rays, tdist, rand_deg, N, lv.S, n, mloops, m->std_scale);
     if (rc) return rc;
@@ -466,7 +468,7 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     }
     {
         ProfScope ps(&m->prof, NLR_K_ENCODE, st);
-        if ((rc = nlr_launch_encode(cp, lv.gp, lv.re_weights, feat, st))) return rc;
+        if ((rc = nlr_launch_encode(cp, lv.gp, lv.re_weights, feat, piece_major, st))) return rc;
     }
     if (rgb) {
         NLR_CHECK_ARG(rays->viewdirs != nullptr, "NerfMLP: viewdirs is NULL");
@@ -482,6 +484,7 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     MlpParams P;
     memset(&P, 0, sizeof(P));
     P.feat = feat;
+    P.feat_piece_major = piece_major;
     P.M = N * lv.S;
     P.S = lv.S;
     P.F = lv.F;
@@ -522,7 +525,8 @@ extern "C" int nlr_mlp_level(const NlrModel *m, uint32_t level, const NlrRays *r
     float *sem = semantic ? semantic : (lv.K ? c.take((size_t)N * lv.S * lv.K) : nullptr);
     if (c.off > workspace_bytes || (!workspace && c.off))
         NLR_FAIL(NLR_ERR_WORKSPACE, "mlp_level: workspace %zu B < needed %zu B", workspace_bytes, c.off);
-    return run_mlp_level(m, lv, rays, tdist, N, sample_n, sample_m, rand_deg, feat, rb, density, rgb, sem, intensity, nullptr, st);
+    return run_mlp_level(m, lv, rays, tdist, N, sample_n, sample_m, rand_deg, feat, rb, density, rgb, sem, intensity, nullptr, st,
+                         features == nullptr);
 }
 
 // ---- Model.forward ----------------------------------------------------------------------------------
@@ -572,7 +576,7 @@ extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t 
             sem = lv.K ? (ho.semantic ? ho.semantic : c.take((size_t)N * S * lv.K)) : nullptr;
             inten = lv.use_int ? (ho.intensity ? ho.intensity : c.take((size_t)N * S)) : nullptr;
         }
-        rc = run_mlp_level(m, lv, rays, tdist, N, n, mloops, cfg->rand_deg[l], feat, rb, density, rgb, sem, inten, nullptr, st);
+        rc = run_mlp_level(m, lv, rays, tdist, N, n, mloops, cfg->rand_deg[l], feat, rb, density, rgb, sem, inten, nullptr, st, true);
         if (rc) return rc;
         {
             ProfScope ps(&m->prof, NLR_K_COMPOSITE, st);

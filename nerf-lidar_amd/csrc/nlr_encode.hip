@@ -247,7 +247,8 @@ __device__ __forceinline__ float nlr_group8_sum(float v) {
 }
 
 template <typename T, int C>
-__global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat) {
+__global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat,
+                                                          int piece_major) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = cp.N * cp.S;
     uint32_t m = gt >> 3;
@@ -279,7 +280,10 @@ __global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridPar
 #pragma unroll
         for (int c = 0; c < C; ++c) a[c] = nlr_group8_sum(a[c]);
         if (in && j == (l & 7)) {  // spread the row stores over the lanes of the group
-            float *f = feat + (size_t)m * gp.L * C + l * C;
+            // piece_major (C == 4, the fused path's internal layout): [L][M][4] - the 8 samples of a wave write one 128-byte
+            // run per level and the MLP kernel's lanes (= samples) read 16 B each from consecutive addresses; the row-major
+            // [M, L*C] form (public nlr_mlp_level `features`) leaves both sides with 16-byte pieces at a 160-byte stride.
+            float *f = (piece_major && C == 4) ? feat + ((size_t)l * M + m) * 4 : feat + (size_t)m * gp.L * C + l * C;
 #pragma unroll
             for (int c = 0; c < C; ++c) f[c] = a[c] * inv_n;
         }
@@ -425,11 +429,11 @@ int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist
     return NLR_OK;
 }
 
-int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, hipStream_t st) {
+int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, int piece_major, hipStream_t st) {
     const uint32_t M = cp.N * cp.S;
     if (cp.n <= 8) {  // multisample-parallel mapping
         dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
-#define NLR_ENC8(T, C) hipLaunchKernelGGL((nlr_encode8_kernel<T, C>), grid8, block8, 0, st, cp, gp, re_weights, feat)
+#define NLR_ENC8(T, C) hipLaunchKernelGGL((nlr_encode8_kernel<T, C>), grid8, block8, 0, st, cp, gp, re_weights, feat, piece_major)
         if (gp.table_dtype == 0) {
             switch (gp.C) {
                 case 1: NLR_ENC8(float, 1); break;

@@ -33,7 +33,8 @@ struct TileH {
 };
 
 struct MlpParams {
-    const float *feat;      // [M, F] f32
+    const float *feat;      // [M, F] f32, or [F/4][M][4] when feat_piece_major
+    int feat_piece_major;
     uint32_t M, S, F;       // samples, samples per ray, feature count
     // Weight tape: every GEMM's A fragments (1 KiB each: 64 lanes x 16 B) in consumption order
     // D0, D2, [H1, H2], V0, V1, V2..V(D-1), RGB (fragments output-tile-major); each GEMM padded to whole 32 KiB chunks.
@@ -61,7 +62,8 @@ int nlr_launch_resample(const float *prev_sdist, const float *prev_weights, uint
                         const float *far, float lam, uint32_t N, float *sdist, float *tdist, hipStream_t st);
 int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist, const float *rand_deg, uint32_t N,
                          uint32_t S, uint32_t n, uint32_t mloops, float std_scale);
-int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, hipStream_t st);
+// piece_major: features as [F/4][M][4] (only honoured by the 8-lane kernel with C == 4; see nlr_encode8_kernel)
+int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, int piece_major, hipStream_t st);
 int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1, const float *b1, const float *w2, float b2,
                     float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st);
 int nlr_launch_direnc(const DirEncParams &P, hipStream_t st);

@@ -426,7 +426,9 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         for (int g = 0; g < FG; ++g) {
             const uint32_t f0 = 8 * g + 4 * h;
             fv[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (f0 + 4 <= P.F) fv[g] = *reinterpret_cast<const f32x4 *>(fp + f0);
+            if (f0 + 4 <= P.F)
+                fv[g] = P.feat_piece_major ? *reinterpret_cast<const f32x4 *>(P.feat + ((size_t)(f0 >> 2) * P.M + sc) * 4)
+                                           : *reinterpret_cast<const f32x4 *>(fp + f0);
         }
         const uint32_t ray = sc / P.S;
 #pragma unroll
