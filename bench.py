@@ -133,7 +133,8 @@ def main():
         step()
     barrier()
     L = _lib.lib()
-    L.nlr_profile_begin(model._handle)  # HIP events on the launch stream around every kernel of the timed steps
+    if not os.environ.get("NLR_BENCH_NOPROF"):  # (diagnostic switch: what do the HIP events themselves cost?)
+        L.nlr_profile_begin(model._handle)  # HIP events on the launch stream around every kernel of the timed steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img = step()
