@@ -73,8 +73,8 @@ def cpu_baseline(mc, sd, batch_np, n_rays, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--precision", type=int, default=_lib.PREC_FAST)
     ap.add_argument("--log2-hashmap", type=int, default=None, help="shrink the hash tables (debug only)")
