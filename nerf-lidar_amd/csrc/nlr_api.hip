@@ -312,7 +312,7 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
         char nm[64];
         snprintf(nm, sizeof(nm), "lin_second_stage_%u", l);
         if ((rc = check_linear(d.view[l], lv.W, lv.W, nm))) return rc;
-        tb.add(mat_from(d.view[l], 0, lv.W), lv.W, lv.W, view, true);
+        tb.add(mat_from(d.view[l], 0, lv.W), lv.W, lv.W, view);
         push_bias(d.view[l].bias, lv.W, lv.W);
     }
     if ((rc = check_linear(d.rgb_layer, 3, lv.W, "rgb_layer"))) return rc;

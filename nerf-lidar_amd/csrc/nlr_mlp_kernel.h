@@ -268,7 +268,7 @@ __device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, f32
         nlr_pad<(OT * KG * FPS) % NLR_CHUNK_FRAGS, (PAR0 + nlr_nch(OT, KG, FPS) - 1) & 1>(tp);
     }
 }
-// EVEN: the GEMM is followed by one padding chunk when its chunk count is odd (keeps the parity of a runtime layer loop)
+// EVEN (unused since the LDS-DMA refill, kept for experiments): one padding chunk after a GEMM with an odd chunk count
 // NP: number of epilogue pieces per output tile
 template <int OT, int KG, int FPS, int NP, int PAR0, bool EVEN = false, class Init, class Step, class Epi>
 __device__ __forceinline__ void nlr_gemm(Tape &tp, const Init &init, const Step &step, const Epi &epi) {
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     constexpr int P_H2 = P_H1 + (HT > 0 ? nlr_nch(HT, BT * KU, CF) : 0);
     constexpr int P_V0 = P_H2 + (HT > 0 ? nlr_nch(1, HT * KU, CF) : 0);
     constexpr int P_V1 = P_V0 + nlr_nch(WT, (BT + 1) * KV, 1);
-    constexpr int P_VL = P_V1 + nlr_nch(WT, (WT + BT + 1) * KV, 1);  // layers >= 2 occupy an even number of chunks each
+    constexpr int P_VL = P_V1 + nlr_nch(WT, (WT + BT + 1) * KV, 1);
 
     // ---- persistent workgroup: one per CU, tiles (4 waves x 32 samples) taken round-robin.  The bias block is staged
     // once, the weight tape streams round and round (its read-ahead runs across the tile seam into chunk 0 of the next
@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         uint32_t l = 2;
         for (; l + 1 < P.depth; l += 2) {
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm_pipe<WT, WT * 2, 8, NPP, PIPE, P_VL & 1, true>(
+            nlr_gemm_pipe<WT, WT * 2, 8, NPP, PIPE, P_VL & 1>(
                 tp, cx, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 },
                 [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); },
                 [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(y[WT - 1], cy); });
-            nlr_gemm_pipe<WT, WT * 2, 8, NPP, PIPE, P_VL & 1, true>(
+            nlr_gemm_pipe<WT, WT * 2, 8, NPP, PIPE, P_VL & 1>(
                 tp, cy, [&](auto o) { return nlr_bias_tile(bl + WT * 32, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         }
         if (l < P.depth) {  // odd number of hidden layers: one more, result moved back into y
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm_pipe<WT, WT * 2, 8, NPP, false, P_VL & 1, true>(
+            nlr_gemm_pipe<WT, WT * 2, 8, NPP, false, P_VL & 1>(
                 tp, cx, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
                     constexpr int G = decltype(g)::value;
@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
             [&](auto o, auto, const f32x16 &a) { y[decltype(o)::value] = nlr_act<true>(a); });
         for (uint32_t l = 2; l < P.depth; ++l) {
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm<WT, WT * 4, 1, 1, P_VL & 1, true>(
+            nlr_gemm<WT, WT * 4, 1, 1, P_VL & 1>(
                 tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
                 [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, WT>(a, f0, y); },
                 [&](auto o, auto, const f32x16 &a) { x[decltype(o)::value] = nlr_act<true>(a); });
