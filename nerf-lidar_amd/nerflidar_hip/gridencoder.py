@@ -1,12 +1,21 @@
-"""Drop-in for the reference's `gridencoder` package on MI355X.
+"""The reference's `gridencoder` package surface on MI355X (operator row a-7).
 
-Mirrors Z/gridencoder/grid.py: the `_backend` functions (`grid_encode_forward`,
-`grid_encode_backward`; bindings.cpp:5-7), the autograd `_grid_encode` Function (grid.py:24-90) and
-the `GridEncoder` module (grid.py:96-174) with the same constructor, attributes (`output_dim,
-num_levels, grid_sizes, idx, embeddings, offsets, init_std`) and `forward(inputs, bound=1)`.
-All arithmetic happens in libnerflidar_hip.so; a missing library or a non-GPU tensor raises.
+Public names and call signatures are the reference's, because callers import them:
+  `_backend.grid_encode_forward / grid_encode_backward`   pybind module, Z/gridencoder/src/bindings.cpp:5-7, gridencoder.h:12-13
+  `grid_encode(...)`, `_grid_encode`                      autograd op, Z/gridencoder/grid.py:24-93
+  `GridEncoder(...)`                                      nn.Module, Z/gridencoder/grid.py:96-174 (constructor keywords, the
+                                                          `embeddings` parameter, buffers `offsets / idx / grid_sizes`,
+                                                          attributes `output_dim / num_levels / level_dim / per_level_scale /
+                                                          base_resolution / init_std`, `forward(inputs, bound=1)`)
+Everything behind those names is organised differently here: one immutable `GridSpec` owns the level table (built by the
+same `weights.level_table` the fused render path uses) and travels through the autograd context; the operator writes
+[B, L*C] directly (no [L, B, C] staging + permute) and keeps its offsets on the host, so a call never synchronises.
+All arithmetic happens in libnerflidar_hip.so; a missing library or a non-GPU tensor raises (no CPU fallback).
 """
 from __future__ import annotations
+
+import math
+from dataclasses import dataclass
 
 import numpy as np
 import torch
@@ -14,86 +23,121 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import _lib
+from .weights import level_table
 
-_gridtype_to_id = {'hash': 0, 'tiled': 1}
-_interp_to_id = {'linear': 0, 'smoothstep': 1}
+GRIDTYPES = ("hash", "tiled")          # ids as in gridencoder.cu:66-84 (0: hash once the dense walk overflows, 1: tiled)
+INTERPOLATIONS = ("linear", "smoothstep")
 
 
-def _require_cuda(t: torch.Tensor, name: str):
+def _device_operand(t: torch.Tensor, name: str) -> None:
+    """The checks of gridencoder.cu:15-19 (CHECK_CUDA / CHECK_CONTIGUOUS), as RuntimeError like TORCH_CHECK."""
     if not t.is_cuda:
-        raise RuntimeError(f"{name} must be a CUDA tensor")  # gridencoder.cu:15 CHECK_CUDA
+        raise RuntimeError(f"{name} must be a CUDA tensor")
     if not t.is_contiguous():
-        raise RuntimeError(f"{name} must be a contiguous tensor")  # gridencoder.cu:16
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+def _host_offsets(offsets) -> torch.Tensor:
+    """int32 level offsets on the host: the launcher derives per-level constants from them (include/nerflidar_hip.h)."""
+    if isinstance(offsets, torch.Tensor):
+        return offsets.detach().to("cpu", torch.int32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(offsets, np.int32))
 
 
 class _Backend:
-    """Same call signatures as the pybind module `_gridencoder` (gridencoder.h:12-15)."""
+    """Positional signatures of the pybind module `_gridencoder` (gridencoder.h:12-13) + one trailing layout switch:
+    0 = the reference's [L, B, C] outputs / gradients, 1 = [B, L*C] (what `GridEncoder.forward` returns anyway)."""
 
     @staticmethod
     def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
                             interp, out_layout=0):
-        for n, t in (("inputs", inputs), ("embeddings", embeddings), ("outputs", outputs)):
-            _require_cuda(t, n)
+        _device_operand(inputs, "inputs")
+        _device_operand(embeddings, "embeddings")
+        _device_operand(outputs, "outputs")
         if inputs.dtype != torch.float32 or outputs.dtype != torch.float32:
             raise RuntimeError("inputs/outputs must be float32 tensors")
-        if embeddings.dtype not in (torch.float32, torch.float16):
+        half = {torch.float32: 0, torch.float16: 1}.get(embeddings.dtype)
+        if half is None:
             raise RuntimeError("embeddings must be a floating tensor (float32 or float16)")
-        off = offsets.detach().to("cpu", torch.int32).contiguous()  # host copy: see include/nerflidar_hip.h
-        rc = _lib.lib().nlr_grid_encode_forward(
-            _lib.ptr(inputs), _lib.ptr(embeddings), 0 if embeddings.dtype == torch.float32 else 1,
-            _lib.ptr(off), _lib.ptr(outputs), B, D, C, L, float(S), int(H), _lib.ptr(dy_dx), int(gridtype),
-            int(bool(align_corners)), int(interp), int(out_layout), _lib.current_stream())
-        _lib.check(rc, "grid_encode_forward")
+        off = _host_offsets(offsets)
+        _lib.check(_lib.lib().nlr_grid_encode_forward(
+            _lib.ptr(inputs), _lib.ptr(embeddings), half, _lib.ptr(off), _lib.ptr(outputs), B, D, C, L, float(S), int(H),
+            _lib.ptr(dy_dx), int(gridtype), int(bool(align_corners)), int(interp), int(out_layout),
+            _lib.current_stream()), "grid_encode_forward")
 
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                              gridtype, align_corners, interp, grad_layout=0):
-        for n, t in (("grad", grad), ("inputs", inputs), ("grad_embeddings", grad_embeddings)):
-            _require_cuda(t, n)
-        off = offsets.detach().to("cpu", torch.int32).contiguous()
-        rc = _lib.lib().nlr_grid_encode_backward(
+        _device_operand(grad, "grad")
+        _device_operand(inputs, "inputs")
+        _device_operand(grad_embeddings, "grad_embeddings")
+        off = _host_offsets(offsets)
+        _lib.check(_lib.lib().nlr_grid_encode_backward(
             _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(off), _lib.ptr(grad_embeddings), B, D, C, L, float(S), int(H),
             _lib.ptr(dy_dx), _lib.ptr(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp),
-            int(grad_layout), _lib.current_stream())
-        _lib.check(rc, "grid_encode_backward")
+            int(grad_layout), _lib.current_stream()), "grid_encode_backward")
 
 
 _backend = _Backend()
 
 
+@dataclass(frozen=True)
+class GridSpec:
+    """Everything the operator needs besides the tensors: the level table and the three mode switches."""
+    offsets: torch.Tensor     # host int32 [L+1]
+    log2_scale: float         # S of gridencoder.cu:138
+    base_resolution: int      # H
+    gridtype: int = 0
+    align_corners: bool = False
+    interpolation: int = 0
+
+    @property
+    def levels(self) -> int:
+        return int(self.offsets.numel()) - 1
+
+    def encode(self, x01: torch.Tensor, table: torch.Tensor, want_dy_dx: bool):
+        """x01 [B, D] in the unit cube -> ([B, L*C] features, dy_dx or None)."""
+        B, D = x01.shape
+        C = table.shape[1]
+        L = self.levels
+        feats = x01.new_empty(B, L * C, dtype=torch.float32)
+        dy_dx = x01.new_empty(B, L * D * C, dtype=torch.float32) if want_dy_dx else None
+        _backend.grid_encode_forward(x01, table, self.offsets, feats, B, D, C, L, self.log2_scale, self.base_resolution,
+                                     dy_dx, self.gridtype, self.align_corners, self.interpolation, 1)
+        return feats, dy_dx
+
+    def scatter(self, grad: torch.Tensor, x01: torch.Tensor, table: torch.Tensor, dy_dx):
+        """Adjoint of `encode`: (d/d table as f32 [T, C], d/d x01 or None)."""
+        B, D = x01.shape
+        C = table.shape[1]
+        g_table = torch.zeros(table.shape, device=grad.device, dtype=torch.float32)
+        g_x = torch.zeros_like(x01) if dy_dx is not None else None
+        _backend.grid_encode_backward(grad, x01, table, self.offsets, g_table, B, D, C, self.levels, self.log2_scale,
+                                      self.base_resolution, dy_dx, g_x, self.gridtype, self.align_corners,
+                                      self.interpolation, 1)
+        return g_table, g_x
+
+
 class _grid_encode(Function):
+    """Argument order of grid.py:26-27 so that `grid_encode(...)` call sites keep working."""
+
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
                 align_corners=False, interpolation=0):
-        inputs = inputs.contiguous()
-        B, D = inputs.shape
-        L = offsets.shape[0] - 1
-        C = embeddings.shape[1]
-        S = np.log2(per_level_scale)
-        H = base_resolution
-        emb = embeddings.contiguous()
-        # written directly in [B, L*C] (out_layout=1): no [L,B,C] -> permute -> reshape round trip (grid.py:47,57)
-        outputs = torch.empty(B, L * C, device=inputs.device, dtype=torch.float32)
-        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=torch.float32) if calc_grad_inputs else None
-        _backend.grid_encode_forward(inputs, emb, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
-                                     interpolation, out_layout=1)
-        ctx.save_for_backward(inputs, emb, dy_dx)
-        ctx.offsets = offsets
-        ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]
-        ctx.align_corners = align_corners
-        return outputs
+        spec = offsets if isinstance(offsets, GridSpec) else GridSpec(
+            _host_offsets(offsets), math.log2(per_level_scale), int(base_resolution), int(gridtype), bool(align_corners),
+            int(interpolation))
+        x01, table = inputs.contiguous(), embeddings.contiguous()
+        feats, dy_dx = spec.encode(x01, table, bool(calc_grad_inputs))
+        ctx.spec = spec
+        ctx.save_for_backward(x01, table, dy_dx)
+        return feats
 
     @staticmethod
     def backward(ctx, grad):
-        inputs, embeddings, dy_dx = ctx.saved_tensors
-        offsets = ctx.offsets
-        B, D, C, L, S, H, gridtype, interpolation = ctx.dims
-        grad = grad.contiguous().float()
-        grad_embeddings = torch.zeros(embeddings.shape, device=grad.device, dtype=torch.float32)
-        grad_inputs = torch.zeros_like(inputs) if dy_dx is not None else None
-        _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
-                                      grad_inputs, gridtype, ctx.align_corners, interpolation, grad_layout=1)
-        return grad_inputs, grad_embeddings.to(embeddings.dtype), None, None, None, None, None, None, None
+        x01, table, dy_dx = ctx.saved_tensors
+        g_table, g_x = ctx.spec.scatter(grad.contiguous().float(), x01, table, dy_dx)
+        return (g_x, g_table.to(table.dtype)) + (None,) * 7
 
 
 grid_encode = _grid_encode.apply
@@ -104,58 +148,42 @@ class GridEncoder(nn.Module):
                  log2_hashmap_size=19, desired_resolution=None, gridtype='hash', align_corners=False,
                  interpolation='linear', init_std=1e-4):
         super().__init__()
-        if desired_resolution is not None:
-            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
-        self.input_dim = input_dim
-        self.num_levels = num_levels
-        self.level_dim = level_dim
-        self.per_level_scale = per_level_scale
-        self.log2_hashmap_size = log2_hashmap_size
-        self.base_resolution = base_resolution
+        offsets, sizes, per_level_scale = level_table(num_levels, base_resolution, log2_hashmap_size, per_level_scale,
+                                                      desired_resolution, input_dim, align_corners)
+        # plain attributes callers read (ZI/models.py:867-880, train_utils.py hash decay)
+        self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
+        self.per_level_scale, self.base_resolution = per_level_scale, base_resolution
+        self.log2_hashmap_size, self.max_params = log2_hashmap_size, 2 ** log2_hashmap_size
+        self.gridtype, self.gridtype_id = gridtype, GRIDTYPES.index(gridtype)
+        self.interpolation, self.interp_id = interpolation, INTERPOLATIONS.index(interpolation)
+        self.align_corners, self.init_std = align_corners, init_std
         self.output_dim = num_levels * level_dim
-        self.gridtype = gridtype
-        self.gridtype_id = _gridtype_to_id[gridtype]
-        self.interpolation = interpolation
-        self.interp_id = _interp_to_id[interpolation]
-        self.align_corners = align_corners
-        self.init_std = init_std
-
-        resolutions, offsets, offset = [], [], 0
-        self.max_params = 2 ** log2_hashmap_size
-        for i in range(num_levels):
-            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
-            resolution = resolution if align_corners else resolution + 1
-            params_in_level = min(self.max_params, resolution ** input_dim)
-            params_in_level = int(np.ceil(params_in_level / 8) * 8)
-            resolutions.append(resolution)
-            offsets.append(offset)
-            offset += params_in_level
-        offsets.append(offset)
-        self.register_buffer('offsets', torch.from_numpy(np.array(offsets, dtype=np.int32)))
-        # host copy for the launcher (never moves with .cuda(); avoids a D2H sync per call)
-        self._offsets_host = torch.from_numpy(np.array(offsets, dtype=np.int32))
-        idx = torch.empty(offset, dtype=torch.long)
-        for i in range(num_levels):
-            idx[offsets[i]:offsets[i + 1]] = i
-        self.register_buffer('idx', idx)
-        self.register_buffer('grid_sizes', torch.from_numpy(np.array(resolutions, dtype=np.int32)))
-        self.n_params = offsets[-1] * level_dim
-        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        rows = int(offsets[-1])
+        self.n_params = rows * level_dim
+        self.register_buffer('offsets', torch.from_numpy(offsets.copy()))
+        self.register_buffer('grid_sizes', torch.from_numpy(sizes.copy()))
+        # level of every table row (hash-decay regulariser, ZI/models.py:203-223)
+        self.register_buffer('idx', torch.repeat_interleave(torch.arange(num_levels), torch.from_numpy(np.diff(offsets)).long()))
+        self._offsets_host = torch.from_numpy(offsets.copy())  # stays on the host when the module moves
+        self._spec = GridSpec(self._offsets_host, math.log2(per_level_scale), int(base_resolution), self.gridtype_id,
+                              bool(align_corners), self.interp_id)
+        self.embeddings = nn.Parameter(torch.empty(rows, level_dim))
         self.reset_parameters()
 
+    @torch.no_grad()
     def reset_parameters(self):
-        self.embeddings.data.uniform_(-self.init_std, self.init_std)
+        nn.init.uniform_(self.embeddings, -self.init_std, self.init_std)
 
-    def __repr__(self):
-        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
-                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
-                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
-                f"align_corners={self.align_corners} interpolation={self.interpolation}")
+    def extra_repr(self) -> str:
+        finest = self.base_resolution * self.per_level_scale ** (self.num_levels - 1)
+        return (f"{self.input_dim}-D {self.gridtype} grid, {self.num_levels} levels x {self.level_dim} channels, "
+                f"resolution {self.base_resolution}..{round(finest)} (x{self.per_level_scale:.4f} per level), "
+                f"table {tuple(self.embeddings.shape)}, {self.interpolation} interpolation"
+                f"{', align_corners' if self.align_corners else ''}")
 
     def forward(self, inputs, bound=1):
-        inputs = (inputs + bound) / (2 * bound)
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.view(-1, self.input_dim)
-        outputs = grid_encode(inputs, self.embeddings, self._offsets_host, self.per_level_scale, self.base_resolution,
-                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id)
-        return outputs.view(prefix_shape + [self.output_dim])
+        lead = inputs.shape[:-1]
+        x01 = ((inputs + bound) / (2 * bound)).reshape(-1, self.input_dim)  # [-bound, bound] -> unit cube (grid.py:162)
+        feats = grid_encode(x01, self.embeddings, self._spec, self.per_level_scale, self.base_resolution,
+                            x01.requires_grad)
+        return feats.reshape(*lead, self.output_dim)

@@ -281,57 +281,93 @@ class _SingleProcess:
         return t
 
 
+def _chunk_plan(total: int, chunk: int, world: int, rank: int):
+    """Static schedule of a render: for every chunk of `chunk` rays, (first ray, rays in the chunk, this process's row range
+    inside the chunk after zero-ray padding to a multiple of the process count).  ZI/models.py:1416-1437."""
+    plan = []
+    for first in range(0, total, chunk):
+        count = min(chunk, total - first)
+        share = -(-count // world)
+        plan.append((first, count, rank * share, (rank + 1) * share))
+    return plan
+
+
+def _rows(flat: Dict[str, torch.Tensor], first: int, count: int, lo: int, hi: int) -> Dict[str, torch.Tensor]:
+    """Rows [lo, hi) of the zero-padded chunk [first, first + count) of every ray tensor."""
+    real = max(min(hi, count) - lo, 0)  # rows of this share that are real rays; the rest is padding
+    out = {}
+    for k, v in flat.items():
+        part = v[first + lo:first + lo + real]
+        if real < hi - lo:  # zero rays, as the reference appends them
+            part = torch.cat([part, v.new_zeros((hi - lo - real,) + tuple(v.shape[1:]))])
+        out[k] = part
+    return out
+
+
+class _Assembler:
+    """Writes each chunk's (gathered, un-padded) tensors into whole-render buffers allocated on first sight of a key."""
+
+    def __init__(self, total: int):
+        self.total = total
+        self.buffers: Dict[str, object] = {}
+
+    def put(self, key: str, first: int, value):
+        if isinstance(value, list):  # per-level ray bundles: kept as parts, only a few rays of them survive
+            slot = self.buffers.setdefault(key, [[] for _ in value])
+            for parts, v in zip(slot, value):
+                parts.append(v)
+            return
+        buf = self.buffers.get(key)
+        if buf is None:
+            buf = self.buffers[key] = value.new_empty((self.total,) + tuple(value.shape[1:]))
+        buf[first:first + value.shape[0]] = value
+
+
 @torch.no_grad()
 def render_image(model: Model, accelerator, batch, rand, config, train_frac=1, verbose=True, return_weights=False,
                  image=True, render_instance=False, instance_id=None):
-    """ZI/models.py:1379-1507: flatten, chunk by `config.render_chunk_size`, pad to a multiple of the process
-    count, rank slice, forward, gather, strip pad, concat, reshape.  `accelerator` may be None (one process)
-    or any object with `process_index`, `num_processes`, `gather` (accelerate.Accelerator works)."""
+    """Signature and result of ZI/models.py:1379-1507.  The sweep / image is rendered chunk by chunk
+    (`config.render_chunk_size` rays); with several processes each renders a contiguous share of every chunk and
+    `accelerator.gather` reassembles it.  `accelerator` may be None (one process) or any object with `process_index`,
+    `num_processes`, `gather` (accelerate.Accelerator works).  For LiDAR sweeps on several GPUs prefer
+    `sharding.render_sweep_sharded`: one collective per sweep instead of one per key per chunk."""
     if render_instance:
         raise NotImplementedError("render_instance (obj_rendering) is outside the fused path")
     acc = accelerator or _SingleProcess()
+    world, rank = acc.num_processes, acc.process_index
+    lead = tuple(batch["origins"].shape[:2]) if image else (batch["origins"].shape[0],)
+    total = int(np.prod(lead))
+    flat = {k: v.reshape(total, -1) for k, v in batch.items() if v is not None}
     model.eval()
-    if image:
-        height, width = batch["origins"].shape[:2]
-        num_rays = height * width
-    else:
-        num_rays = batch["origins"].shape[0]
-    batch = {k: v.reshape((num_rays, -1)) for k, v in batch.items() if v is not None}
-    rank, world = acc.process_index, acc.num_processes
-    chunks = []
-    for idx0 in range(0, num_rays, config.render_chunk_size):
-        cb = {k: v[idx0:idx0 + config.render_chunk_size] for k, v in batch.items()}
-        actual = cb["origins"].shape[0]
-        rem = actual % world
-        padding = world - rem if rem else 0
-        if padding:
-            cb = {k: torch.cat([v, torch.zeros_like(v[-padding:])], dim=0) for k, v in cb.items()}
-        per = cb["origins"].shape[0] // world
-        cb = {k: v[rank * per:(rank + 1) * per] for k, v in cb.items()}
-        renderings, ray_history = model(rand, cb, train_frac=train_frac, compute_extras=True, zero_glo=True)
-        gather = lambda v: acc.gather(v.contiguous())[:-padding] if padding > 0 else acc.gather(v.contiguous())
-        renderings = [{k: gather(v) for k, v in r.items()} for r in renderings]
-        cr = renderings[-1]
-        for k in renderings[0]:
-            if k.startswith("ray_"):
-                cr[k] = [r[k] for r in renderings]
+    out = _Assembler(total)
+    for first, count, lo, hi in _chunk_plan(total, config.render_chunk_size, world, rank):
+        renderings, ray_history = model(rand, _rows(flat, first, count, lo, hi), train_frac=train_frac,
+                                        compute_extras=True, zero_glo=True)
+
+        def whole(t):  # this process's share -> the chunk's real rays
+            t = t.contiguous()
+            return t if world == 1 else acc.gather(t)[:count]
+
+        for key, val in renderings[-1].items():
+            if key.startswith("ray_"):
+                out.put(key, first, [whole(level[key]) for level in renderings])
+            else:
+                out.put(key, first, whole(val))
         if return_weights:
-            cr["weights"] = gather(ray_history[-1]["weights"])
-        chunks.append(cr)
+            out.put("weights", first, whole(ray_history[-1]["weights"]))
     rendering = {}
-    for k in chunks[0].keys():
-        if isinstance(chunks[0][k], list):
-            rendering[k] = [torch.cat([c[k][i] for c in chunks]) for i in range(len(chunks[0][k]))]
+    for key, buf in out.buffers.items():
+        if isinstance(buf, list):
+            rendering[key] = [torch.cat(parts) for parts in buf]
+        elif "hash" in key:
+            rendering[key] = buf
         else:
-            rendering[k] = torch.cat([c[k] for c in chunks])
-    for k, z in rendering.items():
-        if not k.startswith("ray_") and "hash" not in k:
-            rendering[k] = z.reshape((height, width) + z.shape[1:]) if image else z.reshape(num_rays, -1)
-    keys = [k for k in rendering if k.startswith("ray_")]
-    if keys:
-        nr = rendering[keys[0]][0].shape[0]
-        ray_idx = torch.randperm(nr)[:config.vis_num_rays]
-        for k in keys:
-            rendering[k] = [r[ray_idx.to(r.device)] for r in rendering[k]]
+            rendering[key] = buf.reshape(lead + tuple(buf.shape[1:])) if image else buf.reshape(total, -1)
+    bundles = [k for k in rendering if k.startswith("ray_")]
+    if bundles:  # the same random subset of rays for every bundle (models.py:1495-1503)
+        have = rendering[bundles[0]][0].shape[0]
+        pick = torch.randperm(have)[:config.vis_num_rays]
+        for k in bundles:
+            rendering[k] = [level[pick.to(level.device)] for level in rendering[k]]
     model.train()
     return rendering

@@ -15,27 +15,28 @@ from . import synth
 from .config import MLPConfig, ModelConfig
 
 
-def grid_layout(cfg: MLPConfig, input_dim: int = 3, align_corners: bool = False):
-    """Level offset table of Z/gridencoder/grid.py:122-142.
+def level_table(num_levels: int, base_resolution: int, log2_hashmap_size: int, per_level_scale: float = 2.0,
+                desired_resolution=None, input_dim: int = 3, align_corners: bool = False):
+    """Rows of the multi-resolution table, level by level (Z/gridencoder/grid.py:105-106,122-142).
 
+    Level l has G_l = ceil(H * s^l) (+1 unless align_corners) grid points per axis and stores min(2^log2_hashmap_size, G_l^D)
+    rows rounded up to a multiple of 8; `desired_resolution` (if given) fixes s so that the finest level reaches it.
     Returns (offsets int32 [L+1], grid_sizes int32 [L], per_level_scale float).
     """
-    L = cfg.grid_num_levels
-    # grid.py:105-106 (desired_resolution overrides per_level_scale)
-    per_level_scale = np.exp2(np.log2(cfg.grid_disired_resolution / cfg.grid_base_resolution) / (L - 1)) \
-        if L > 1 else 1.0
-    max_params = 2 ** cfg.grid_log2_hashmap_size
-    offsets, sizes, off = [], [], 0
-    for i in range(L):
-        res = int(np.ceil(cfg.grid_base_resolution * per_level_scale ** i))
-        res = res if align_corners else res + 1
-        n = min(max_params, res ** input_dim)
-        n = int(np.ceil(n / 8) * 8)
-        sizes.append(res)
-        offsets.append(off)
-        off += n
-    offsets.append(off)
-    return np.asarray(offsets, np.int32), np.asarray(sizes, np.int32), float(per_level_scale)
+    if desired_resolution is not None:
+        per_level_scale = float(np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))) if num_levels > 1 else 1.0
+    grow = 0 if align_corners else 1
+    sizes = [int(np.ceil(base_resolution * per_level_scale ** l)) + grow for l in range(num_levels)]
+    cap = 2 ** log2_hashmap_size
+    rows = [-(-min(cap, g ** input_dim) // 8) * 8 for g in sizes]
+    offsets = np.concatenate([[0], np.cumsum(rows, dtype=np.int64)])
+    return offsets.astype(np.int32), np.asarray(sizes, np.int32), float(per_level_scale)
+
+
+def grid_layout(cfg: MLPConfig, input_dim: int = 3, align_corners: bool = False):
+    """`level_table` for an MLP's gin-configured grid (ZI/models.py:867-880)."""
+    return level_table(cfg.grid_num_levels, cfg.grid_base_resolution, cfg.grid_log2_hashmap_size, 2.0,
+                       cfg.grid_disired_resolution, input_dim, align_corners)
 
 
 def mlp_param_shapes(cfg: MLPConfig) -> List[Tuple[str, Tuple[int, int], bool]]:
