@@ -38,8 +38,8 @@ enum {
 /* MLP arithmetic (NlrModelDesc.mlp_precision) */
 enum {
     NLR_PREC_F32 = 0,   /* every layer on exact-f32 MFMA (v_mfma_f32_32x32x2_f32): reference-grade */
-    NLR_PREC_MIXED = 1, /* density/semantic/intensity layers f32 MFMA, view-MLP bf16 MFMA (default) */
-    NLR_PREC_FAST = 2   /* density/semantic/intensity layers split-bf16 (hi+lo, 3 MFMAs), view bf16 */
+    NLR_PREC_MIXED = 1, /* density/semantic/intensity layers f32 MFMA, view-MLP bf16 MFMA */
+    NLR_PREC_FAST = 2   /* density/semantic/intensity layers split-bf16 (hi+lo, 3 MFMAs), view bf16: the default of the Python host side, bench.py and smoke() */
 };
 
 const char *nlr_last_error(void);
@@ -137,6 +137,9 @@ typedef struct NlrModelDesc {        /* ZI/models.py:Model (31-58) */
 } NlrModelDesc;
 
 typedef struct NlrModel NlrModel;
+/* Packs the weights and uploads them with copies enqueued on `stream`; returns once they have completed (the host staging
+ * buffers are temporaries).  The model is bound to the device that is current at creation (its CU count sizes the
+ * persistent grid of the MLP kernel). */
 int nlr_model_create(const NlrModelDesc *desc, NlrModel **out, void *stream);
 void nlr_model_destroy(NlrModel *m);
 /* Re-point a level's hash table (e.g. after an optimizer step re-allocated the parameter). */
@@ -181,6 +184,13 @@ typedef struct NlrOut {              /* renderings[-1] (render.py:219-284); any 
     float *acc, *distance_mean, *distance_median, *distance_percentile_5, *distance_percentile_95; /* [N] */
     int32_t *labels;                 /* [N] argmax_c semantic (render_lidar.py:158-159) */
     float *points;                   /* [N,3] (o + depth*d)/scale_factor (render_lidar.py:142-156) */
+    /* One 7-float record per ray: depth, intensity, acc, rgb[3], label (as float; exact below 2^24) -- the tile a rank
+     * contributes to the all-gathered range image, written by the compositing kernel itself.  Record of ray i:
+     * packed_h == 0: row i.  packed_h = H > 0: the batch is a beam-major [H, packed_w] azimuth sector (ray = beam * packed_w
+     * + column) and the record goes to row column * H + beam, i.e. the tile is [packed_w, H, 7] (azimuth-major), so that
+     * the rank-major concatenation an all-gather produces IS the [W, H, 7] sweep image, with no reassembly pass. */
+    float *packed;
+    uint32_t packed_h, packed_w;
     NlrLevelOut history[NLR_MAX_LEVELS];
 } NlrOut;
 

@@ -71,6 +71,9 @@ struct NlrModel {
     LevelModel lv[NLR_MAX_LEVELS];
     float dilation_multiplier, dilation_bias, anneal_slope, resample_padding, power_lambda, std_scale, bg;
     uint32_t opaque, prec;
+    int device = 0;
+    uint32_t cus = 0;          // compute units of `device`: the MLP kernel runs one persistent workgroup per CU
+    hipStream_t up = nullptr;  // stream the weight uploads of nlr_model_create are enqueued on
     std::vector<void *> allocs;
     mutable Profile prof;
 };
@@ -79,7 +82,7 @@ static int dev_upload(NlrModel *m, const void *host, size_t bytes, void **out) {
     void *p = nullptr;
     NLR_HIP(hipMalloc(&p, bytes ? bytes : 16));
     m->allocs.push_back(p);
-    if (bytes) NLR_HIP(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+    if (bytes) NLR_HIP(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, m->up));  // pageable source: staged before return
     *out = p;
     return NLR_OK;
 }
@@ -328,12 +331,21 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
 }
 
 extern "C" int nlr_model_create(const NlrModelDesc *desc, NlrModel **out, void *stream) {
-    (void)stream;
     NLR_CHECK_ARG(desc && out, "model_create: NULL argument");
     NLR_CHECK_ARG(desc->num_levels >= 1 && desc->num_levels <= NLR_MAX_LEVELS, "num_levels %u outside [1,%d]", desc->num_levels,
                   NLR_MAX_LEVELS);
     NLR_CHECK_ARG(desc->mlp_precision <= NLR_PREC_FAST, "unknown mlp_precision %u", desc->mlp_precision);
     NlrModel *m = new NlrModel();
+    m->up = (hipStream_t)stream;
+    {
+        int n = 0;
+        if (hipGetDevice(&m->device) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, m->device) != hipSuccess || n <= 0) {
+            delete m;
+            NLR_FAIL(NLR_ERR_HIP, "model_create: cannot query the current device");
+        }
+        m->cus = (uint32_t)n;
+    }
     m->num_levels = desc->num_levels;
     m->dilation_multiplier = desc->dilation_multiplier;
     m->dilation_bias = desc->dilation_bias;
@@ -368,6 +380,10 @@ extern "C" int nlr_model_create(const NlrModelDesc *desc, NlrModel **out, void *
             nlr_model_destroy(m);
             return rc;
         }
+    }
+    if (hipStreamSynchronize(m->up) != hipSuccess) {
+        nlr_model_destroy(m);
+        NLR_FAIL(NLR_ERR_HIP, "model_create: weight upload failed");
     }
     *out = m;
     return NLR_OK;
@@ -505,7 +521,7 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     P.sem = sem;
     P.inten = (lv.use_int && inten) ? inten : nullptr;
     ProfScope ps(&m->prof, NLR_K_MLP, st);
-    return nlr_launch_mlp(P, lv.W, lv.WB, lv.HT, lv.prec, st);
+    return nlr_launch_mlp(P, lv.W, lv.WB, lv.HT, lv.prec, m->cus, st);
 }
 
 extern "C" int nlr_mlp_level(const NlrModel *m, uint32_t level, const NlrRays *rays, const float *tdist, uint32_t N,

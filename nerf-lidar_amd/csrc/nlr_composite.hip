@@ -137,6 +137,16 @@ __global__ void __launch_bounds__(256) nlr_composite_kernel(CompositeParams P) {
                 P.o_points[(size_t)ray * 3 + c] = (P.origins[(size_t)ray * 3 + c] + depth * P.dirs[(size_t)ray * 3 + c]) / P.scale_factor;
         }
         if (P.o_acc) P.o_acc[ray] = acc;
+        if (P.o_packed) {
+            const uint32_t row = P.pk_h ? (ray % P.pk_w) * P.pk_h + ray / P.pk_w : ray;
+            float *pk = P.o_packed + (size_t)row * 7;
+            pk[0] = depth;
+            pk[1] = P.inten ? sint : 0.0f;
+            pk[2] = acc;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pk[3 + c] = srgb[c] + bgw * P.bg;
+            pk[6] = (float)label;
+        }
     }
     if (!P.extras) return;  // uniform across the block
 
@@ -239,6 +249,12 @@ extern "C" int nlr_composite_level(const float *density, const float *tdist, con
         P.o_p95 = out->distance_percentile_95;
         P.o_labels = out->labels;
         P.o_points = scale_factor > 0 ? out->points : nullptr;
+        P.o_packed = out->packed;
+        P.pk_h = out->packed_h;
+        P.pk_w = out->packed_w;
+        if (out->packed && out->packed_h)
+            NLR_CHECK_ARG(out->packed_w > 0 && (uint64_t)out->packed_h * out->packed_w == N,
+                          "composite: packed tile %u x %u does not match N = %u rays", out->packed_h, out->packed_w, N);
     }
     return nlr_launch_composite(P, (hipStream_t)stream);
 }

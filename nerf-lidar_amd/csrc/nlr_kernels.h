@@ -22,6 +22,8 @@ struct CompositeParams {
     float *weights;  // [N,S] or null
     float *o_rgb, *o_depth, *o_sem, *o_int, *o_acc, *o_dmean, *o_dmed, *o_p5, *o_p95, *o_points, *level_depth;
     int32_t *o_labels;
+    float *o_packed;         // [N, 7] records (see NlrOut.packed)
+    uint32_t pk_h, pk_w;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -67,5 +69,5 @@ int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights
 int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1, const float *b1, const float *w2, float b2,
                     float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st);
 int nlr_launch_direnc(const DirEncParams &P, hipStream_t st);
-int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, hipStream_t st);
+int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, uint32_t cus, hipStream_t st);
 int nlr_launch_composite(const CompositeParams &P, hipStream_t st);

@@ -38,21 +38,15 @@ int nlr_launch_direnc(const DirEncParams &P, hipStream_t st) {
 NLR_FOR_ALL_INSTANCES(NLR_DECL)
 #undef NLR_DECL
 
-int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, hipStream_t st) {
+int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, uint32_t cus, hipStream_t st) {
     NLR_CHECK_ARG(P.M > 0, "mlp: no samples");
     NLR_CHECK_ARG(P.tape && P.tape_chunks > 0, "mlp: weight tape missing");
     NLR_CHECK_ARG(P.bias_all && P.bias_count <= 4096 && P.bias_count % 4 == 0, "mlp: bias block missing or > 4096 floats");
     const uint32_t FG = (P.F + 7) / 8;
     // persistent workgroups: one per CU (112 KiB of LDS each, so one is all a CU holds), tiles of 128 samples round-robin
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        NLR_HIP(hipGetDevice(&dev));
-        NLR_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = n > 0 ? n : 256;
-    }
+    NLR_CHECK_ARG(cus > 0, "mlp: CU count of the model's device is unknown");
     const uint32_t ntiles = (P.M + 127) / 128;
-    dim3 grid(ntiles < (uint32_t)cus ? ntiles : (uint32_t)cus);
+    dim3 grid(ntiles < cus ? ntiles : cus);
     if (WB == 256 && FG == 5) {
 #define NLR_TRY(wt, ht, pr)                                   \
     if (W == wt * 32 && HT == ht && prec == pr) {             \

@@ -62,8 +62,8 @@ class NlrLevelOut(C.Structure):
 
 class NlrOut(C.Structure):
     _fields_ = [(k, c_fp) for k in ("rgb", "depth", "semantic", "intensity", "acc", "distance_mean", "distance_median",
-                                    "distance_percentile_5", "distance_percentile_95", "labels", "points")] + \
-               [("history", NlrLevelOut * NLR_MAX_LEVELS)]
+                                    "distance_percentile_5", "distance_percentile_95", "labels", "points", "packed")] + \
+               [("packed_h", C.c_uint32), ("packed_w", C.c_uint32), ("history", NlrLevelOut * NLR_MAX_LEVELS)]
 
 
 _lib = None

@@ -36,7 +36,7 @@ class Model:
     """
 
     def __init__(self, mc: ModelConfig, state_dict: Dict[str, object], device="cuda:0",
-                 precision: int = _lib.PREC_MIXED, table_dtype=torch.float32):
+                 precision: int = _lib.PREC_FAST, table_dtype=torch.float32):
         if mc.config.instance_obj:
             raise NotImplementedError("instance_obj=True (dynamic-object branch, ZI/models.py:306-315,401-477) "
                                       "is outside the fused path (SURVEY section 8f-1)")
@@ -157,8 +157,13 @@ class Model:
 
     def render_rays(self, batch: Dict[str, torch.Tensor], train_frac: float = 1.0, compute_extras: bool = True,
                     sample_n: int = 7, sample_m: int = 3, want_history: bool = False, scale_factor: float = 0.0,
-                    rand_jitter: Optional[List[torch.Tensor]] = None, rand_deg: Optional[List[torch.Tensor]] = None):
-        """One `nlr_render_rays` call.  Returns (rendering dict of the last level, list of per-level dicts)."""
+                    rand_jitter: Optional[List[torch.Tensor]] = None, rand_deg: Optional[List[torch.Tensor]] = None,
+                    packed: Optional[torch.Tensor] = None):
+        """One `nlr_render_rays` call.  Returns (rendering dict of the last level, list of per-level dicts).
+
+        packed: optional float32 CUDA buffer for the 7-float-per-ray records (depth, intensity, acc, rgb, label) the
+        compositing kernel writes besides the named outputs: shape [n, 7] (ray order) or [wp, H, 7] with wp * H == n
+        (azimuth-major tile of a beam-major [H, wp] sector, see sharding.py); returned as r["packed"]."""
         rays = _lib.NlrRays()
         n = batch["origins"].shape[0]
         keep = []
@@ -189,6 +194,13 @@ class Model:
                 r["labels"] = new(n, dtype=torch.int32)
         for k, t in r.items():
             setattr(out, k, t.data_ptr())
+        if packed is not None:
+            if not (packed.is_cuda and packed.dtype == f32 and packed.is_contiguous() and packed.numel() == n * 7):
+                raise RuntimeError("packed must be a contiguous float32 CUDA tensor with 7 values per ray")
+            out.packed = packed.data_ptr()
+            if packed.dim() == 3:
+                out.packed_w, out.packed_h = int(packed.shape[0]), int(packed.shape[1])
+            r["packed"] = packed
         hist: List[Dict[str, torch.Tensor]] = []
         samples = self.mc.level_samples()
         for li, S in enumerate(samples):

@@ -1,16 +1,24 @@
-"""Azimuth-sector sharding of a LiDAR sweep over the GPUs of one node.
+"""Azimuth-sector sharding of a LiDAR sweep over the GPUs of one node (BASELINE config C4).
 
 Replaces the reference's inference parallelism (ZI/models.py:1425-1437 rank slices of each chunk and
 ZI/models.py:1454-1457 one `accelerator.gather` per output key per chunk, ~12 small all_gathers) by:
-GPU p renders columns [p*W/P, (p+1)*W/P) of every beam, packs its outputs into ONE tile
-[H, W/P, C_pack] and a single all-gather (RCCL over xGMI; `torch.distributed` backend "nccl")
-reassembles the [H, W, C_pack] range image on every rank.  Rays are independent, so the gathered image
-equals the single-GPU image bit for bit.  `render_fn` is injected so the partition / pack / gather /
-reassembly logic is testable on CPU with the gloo backend.
+GPU p renders columns [p*W/P, (p+1)*W/P) of every beam and ONE all-gather (RCCL over xGMI;
+`torch.distributed` backend "nccl") puts the whole sweep on every rank.
+
+Layout.  A rank's tile is AZIMUTH-MAJOR, `[W/P, H, 7]` (7 floats per ray: depth, intensity, acc, rgb[3], label),
+written by the compositing kernel itself (`NlrOut.packed`).  The rank-major concatenation that an all-gather produces is
+then the `[W, H, 7]` image of the sweep: no pack pass before the collective and no transpose after it.  `as_hw` gives the
+`[H, W, 7]` view the ray-drop UNet side indexes.  Rays are independent, so the gathered image equals the one-GPU image
+bit for bit.
+
+Overlap.  `SweepGatherer` issues the collective on a side stream and double-buffers tile and image, so the all-gather of
+sweep i runs under the resampling / proposal / encode kernels of sweep i+1 (the message is 0.9 MB per rank at 8 x 4096
+rays: latency-bound, tens of microseconds).  `render_fn` is injected so that partition, gather and reassembly are
+testable on CPU with the gloo backend.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, Optional
 
 import numpy as np
 import torch
@@ -18,50 +26,111 @@ import torch.distributed as dist
 
 from . import lidar
 
-PACK_KEYS = ("depth", "intensity", "acc", "rgb", "labels")  # 1 + 1 + 1 + 3 + 1 = 7 floats per ray
+RECORD = 7  # depth, intensity, acc, rgb[3], label
+PACK_KEYS = ("depth", "intensity", "acc", "rgb", "labels")
+
+
+def _world(group=None):
+    return (dist.get_world_size(group), dist.get_rank(group)) if dist.is_initialized() else (1, 0)
 
 
 def pack_tile(r: Dict[str, torch.Tensor], height: int, wp: int) -> torch.Tensor:
-    """[H*wp] outputs -> [H, wp, 7] float32 tile (labels travel as float; exact for class ids < 2^24)."""
+    """Beam-major per-ray outputs [H*wp] -> azimuth-major tile [wp, H, 7] (labels travel as float; exact below 2^24).
+    Host-side equivalent of what the compositing kernel writes into `NlrOut.packed`; used where the renderer is a stand-in."""
     n = height * wp
-    cols = []
+    tile = torch.zeros(n, RECORD, device=r["depth"].device)
+    col = 0
     for k in PACK_KEYS:
-        t = r.get(k)
-        if t is None:
-            t = torch.zeros(n, 3 if k == "rgb" else 1, device=r["depth"].device)
-        cols.append(t.reshape(n, -1).float())
-    return torch.cat(cols, dim=1).reshape(height, wp, -1).contiguous()
+        width = 3 if k == "rgb" else 1
+        if r.get(k) is not None:
+            tile[:, col:col + width] = r[k].reshape(n, width).float()
+        col += width
+    return tile.reshape(height, wp, RECORD).permute(1, 0, 2).contiguous()
+
+
+def as_hw(img: torch.Tensor) -> torch.Tensor:
+    """[W, H, 7] sweep image -> [H, W, 7] view (no copy)."""
+    return img.permute(1, 0, 2)
 
 
 def unpack_image(img: torch.Tensor) -> Dict[str, torch.Tensor]:
-    return dict(depth=img[..., 0], intensity=img[..., 1], acc=img[..., 2], rgb=img[..., 3:6],
-                labels=img[..., 6].round().to(torch.int32))
+    """[W, H, 7] sweep image -> dict of [H, W(, 3)] views."""
+    v = as_hw(img)
+    return dict(depth=v[..., 0], intensity=v[..., 1], acc=v[..., 2], rgb=v[..., 3:6], labels=v[..., 6].round().to(torch.int32))
 
 
-def render_sweep_sharded(render_fn: Callable[[Dict[str, torch.Tensor]], Dict[str, torch.Tensor]],
-                         batch_np: Dict[str, np.ndarray], height: int, width: int, device,
-                         group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
-    """Render this rank's azimuth sector and all-gather the range image.  Returns [H, W, 7] on every rank.
+class SweepGatherer:
+    """Double-buffered, side-stream all-gather of azimuth-major tiles.
 
-    batch_np is the FULL sweep's ray batch (host numpy, beam-major): the sector is sliced from it so that the
-    LiDAR `viewdirs` keep the full-sweep Frobenius normalisation (ZI/lidar_utils.py:12) and a sector renders
-    exactly what the same rays render inside a one-GPU sweep.
+        g = SweepGatherer(height, width, device)
+        for i, sweep in enumerate(sweeps):
+            tile = g.tile(i)            # [wp, H, 7] buffer the renderer writes (NlrOut.packed); safe to overwrite
+            render(sweep, packed=tile)
+            g.submit(i)                 # collective on the side stream, behind the render of sweep i
+        img = g.image(i)                # [W, H, 7]; the current stream now waits for gather i
+
+    With one rank (and `force=False`) the tile IS the image and nothing is launched.  On CPU (gloo tests) the collective
+    is issued synchronously."""
+
+    def __init__(self, height: int, width: int, device, group=None, force: bool = False):
+        self.world, self.rank = _world(group)
+        self.group = group
+        self.height, self.width = height, width
+        self.wp = -(-width // self.world)
+        self.device = torch.device(device)
+        self.collective = self.world > 1 or (force and dist.is_initialized())
+        self.cuda = self.device.type == "cuda"
+        mk = lambda *s: torch.zeros(*s, device=self.device)
+        self.tiles = [mk(self.wp, height, RECORD) for _ in range(2)]
+        self.images = [mk(self.world * self.wp, height, RECORD) for _ in range(2)] if self.collective else self.tiles
+        self.side = torch.cuda.Stream(self.device) if (self.cuda and self.collective) else None
+        self.done = [None, None]  # event: gather that last read tiles[b] / wrote images[b] has finished
+
+    def tile(self, i: int) -> torch.Tensor:
+        b = i & 1
+        if self.side is not None and self.done[b] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.done[b])  # gather i-2 still reads this buffer
+        return self.tiles[b]
+
+    def submit(self, i: int) -> None:
+        if not self.collective:
+            return
+        b = i & 1
+        if self.side is None:
+            dist.all_gather_into_tensor(self.images[b], self.tiles[b], group=self.group)
+            return
+        rendered = torch.cuda.Event()
+        rendered.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(rendered)
+            dist.all_gather_into_tensor(self.images[b], self.tiles[b], group=self.group)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.done[b] = ev
+
+    def image(self, i: int) -> torch.Tensor:
+        b = i & 1
+        if self.side is not None and self.done[b] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.done[b])
+        return self.images[b][:self.width]
+
+
+def render_sweep_sharded(render_fn: Callable[..., Dict[str, torch.Tensor]], batch_np: Dict[str, np.ndarray], height: int,
+                         width: int, device, group: Optional[dist.ProcessGroup] = None,
+                         gatherer: Optional[SweepGatherer] = None, index: int = 0) -> torch.Tensor:
+    """Render this rank's azimuth sector and all-gather the sweep.  Returns the [W, H, 7] image on every rank.
+
+    batch_np is the FULL sweep's ray batch (host numpy, beam-major): the sector is sliced from it so that the LiDAR
+    `viewdirs` keep the full-sweep Frobenius normalisation (ZI/lidar_utils.py:12) and a sector renders exactly what the
+    same rays render inside a one-GPU sweep.  `render_fn(batch, packed=tile)` may fill the azimuth-major tile itself
+    (the HIP renderer does) and return None / a dict with "packed"; if it returns per-ray outputs they are packed here.
     """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    sec, wp = lidar.azimuth_sector(batch_np, height, width, rank, world)
+    g = gatherer or SweepGatherer(height, width, device, group)
+    sec, wp = lidar.azimuth_sector(batch_np, height, width, g.rank, g.world)
     batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in sec.items()}
-    tile = pack_tile(render_fn(batch), height, wp)
-    return gather_tiles(tile, width, group)
-
-
-def gather_tiles(tile: torch.Tensor, width: int, group=None, force: bool = False) -> torch.Tensor:
-    """ONE all-gather of the packed [H, W/P, C] tile -> [H, W, C] (pad columns stripped).  `force` runs the collective
-    even with a single rank (rehearsal of the RCCL path on a one-GPU box)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 and not (force and dist.is_initialized()):
-        return tile[:, :width]
-    h, wp, c = tile.shape
-    out = torch.empty(world * h, wp, c, device=tile.device, dtype=tile.dtype)  # rank-major concatenation
-    dist.all_gather_into_tensor(out, tile, group=group)
-    return out.view(world, h, wp, c).permute(1, 0, 2, 3).reshape(h, world * wp, c)[:, :width].contiguous()
+    tile = g.tile(index)
+    r = render_fn(batch, packed=tile)
+    if isinstance(r, dict) and "packed" not in r:
+        tile.copy_(pack_tile(r, height, wp))
+    g.submit(index)
+    return g.image(index)

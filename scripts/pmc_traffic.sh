@@ -1,5 +1,7 @@
 #!/bin/bash
 # HBM traffic of the render kernels: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md, HBM section).
+# Writes gpurun_out/pmc_traffic/summary.json = {"kernel_source_sha": <hash of the sources this binary was built from>,
+# "kernels": {name: {...}}}; copy it to profiles/r02_pmc_traffic.json.  bench.py quotes it only while the hash matches.
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
 mkdir -p $OUT
@@ -8,7 +10,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $GRAFT_R
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
-import csv, glob, collections, json
+import csv, glob, collections, json, sys
+sys.path.insert(0, "nerf-lidar_amd")
+from nerflidar_hip import buildinfo
 res = collections.defaultdict(dict)
 for d in ("fetch", "write", "l2"):
     for f in glob.glob(f"gpurun_out/pmc_traffic/{d}/**/*counter_collection.csv", recursive=True):
@@ -24,5 +28,5 @@ for k, v in res.items():
     if "WRITE_SIZE" in v: v["hbm_write_bytes"] = v["WRITE_SIZE"] * 1024
     if "TCC_HIT_sum" in v: v["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
     print(k, json.dumps(v))
-json.dump(res, open("gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
+json.dump({"kernel_source_sha": buildinfo.kernel_source_sha(), "kernels": res}, open("gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
 PY

@@ -432,6 +432,39 @@ def test_full_size_properties():
     np.testing.assert_array_equal(npy(rs["depth"]), d[idx])
 
 
+def test_c4_sectors_reassemble_the_sweep():
+    """BASELINE config C4 on one GPU: the 8 azimuth sectors of ONE 32x1024 sweep, each rendered alone into its azimuth-major
+    packed tile (written by the compositing kernel, NlrOut.packed), concatenated rank-major (what the all-gather does) ARE
+    the packed image of the sweep rendered in one piece, bit for bit; and the records equal the named outputs."""
+    from nerflidar_hip import sharding
+    from nerflidar_hip.models import Model
+    H, W, P = 32, 1024, 8
+    mc = nconfig.workload("C2", 14)
+    sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
+    model = Model(mc, sd, device=DEV)
+    batch_np = nlidar.synthetic_sweep(width=W, seed=0)
+    whole = torch.empty(W, H, 7, device=DEV)
+    r, _ = model.render_rays({k: cu(v) for k, v in batch_np.items()}, scale_factor=1 / 250, packed=whole)
+    img = sharding.as_hw(whole)
+    for k, sl in (("depth", 0), ("intensity", 1), ("acc", 2)):
+        assert torch.equal(img[..., sl].reshape(-1), r[k])
+    assert torch.equal(img[..., 3:6].reshape(-1, 3), r["rgb"])
+    assert torch.equal(img[..., 6].reshape(-1).to(torch.int32), r["labels"])
+    assert torch.equal(sharding.unpack_image(whole)["labels"].reshape(-1), r["labels"])
+    tiles = []
+    for p in range(P):
+        sec, wp = nlidar.azimuth_sector(batch_np, H, W, p, P)
+        t = torch.empty(wp, H, 7, device=DEV)
+        model.render_rays({k: cu(v) for k, v in sec.items()}, scale_factor=1 / 250, packed=t)
+        tiles.append(t)
+    assert torch.equal(torch.cat(tiles), whole)
+    flat = torch.empty(H * W, 7, device=DEV)  # ray-order records
+    model.render_rays({k: cu(v) for k, v in batch_np.items()}, scale_factor=1 / 250, packed=flat)
+    assert torch.equal(flat.reshape(H, W, 7), img)
+    with pytest.raises(RuntimeError, match="packed"):
+        model.render_rays({k: cu(v) for k, v in batch_np.items()}, packed=torch.empty(5, 7, device=DEV))
+
+
 def test_error_behaviour():
     from nerflidar_hip.models import Model
     mc = nconfig.workload("REF", 12)

@@ -30,7 +30,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.NlrGridDesc) == 56
     assert C.sizeof(_lib.NlrRays) == 64
     assert C.sizeof(_lib.NlrLevelOut) == 64
-    assert C.sizeof(_lib.NlrOut) == 11 * 8 + 4 * 64
+    assert C.sizeof(_lib.NlrOut) == 12 * 8 + 8 + 4 * 64
     assert C.sizeof(_lib.NlrRenderCfg) == 16 + 2 * 32 + 8
 
 
@@ -121,17 +121,22 @@ def _shard_worker(rank, world, port, tmp):
     H, W = 4, 22  # W not divisible by world -> padded columns
     full = nlidar.synthetic_sweep(width=W, seed=1, beams=nlidar.LIDAR_ANGLES[:H])
 
-    def fake_render(b):  # deterministic per-ray function standing in for the HIP renderer
+    def fake_render(b, packed=None):  # deterministic per-ray function standing in for the HIP renderer
         d, o = b["directions"], b["origins"]
         depth = (d * torch.tensor([1.0, 2.0, 3.0])).sum(-1) + o[:, 0]
         return dict(depth=depth, intensity=depth * 0.5, acc=torch.ones_like(depth), rgb=d.abs(),
                     labels=(depth.abs() * 7).to(torch.int32) % 19)
 
-    img = sharding.render_sweep_sharded(fake_render, full, H, W, "cpu")
-    one = sharding.pack_tile(fake_render({k: torch.from_numpy(v) for k, v in full.items()}), H, W)
-    assert img.shape == (H, W, 7)
-    assert torch.equal(img, one), "gathered range image differs from the single-process image"
-    assert torch.equal(sharding.unpack_image(img)["labels"], one[..., 6].to(torch.int32))
+    one_r = fake_render({k: torch.from_numpy(v) for k, v in full.items()})
+    one = sharding.pack_tile(one_r, H, W)  # azimuth-major [W, H, 7]
+    g = sharding.SweepGatherer(H, W, "cpu")
+    for i in range(3):  # double buffering: three sweeps through two buffers
+        img = sharding.render_sweep_sharded(fake_render, full, H, W, "cpu", gatherer=g, index=i)
+        assert img.shape == (W, H, 7)
+        assert torch.equal(img, one), "gathered range image differs from the single-process image"
+    u = sharding.unpack_image(img)
+    assert torch.equal(u["labels"].reshape(-1), one_r["labels"]) and torch.equal(u["depth"].reshape(-1), one_r["depth"])
+    assert torch.equal(sharding.as_hw(img)[..., 3:6].reshape(-1, 3), one_r["rgb"])
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("1")
@@ -147,3 +152,21 @@ def test_sharded_sweep_world2_gloo(tmp_path):
     s.close()
     mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+@pytest.mark.parametrize("extra", [["--gpus", "2"], ["--gpus", "2", "--scaling", "weak"], ["--gpus", "1", "--force-dist"]])
+def test_bench_self_launch_cpu(extra):
+    """`python bench.py --gpus N` without a launcher environment starts its own N ranks (torch.distributed.run children) and
+    prints ONE JSON line; here on CPU ranks (gloo) with the stand-in renderer of --selftest-cpu."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-cpu", "--steps", "3"] + extra,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["selftest"] and d["image_equal"] and d["n_gpus"] == int(extra[1])
+    assert d["shape"] == [64 * (2 if "weak" in extra else 1), 4, 7]
