@@ -82,7 +82,10 @@ static int dev_upload(NlrModel *m, const void *host, size_t bytes, void **out) {
     void *p = nullptr;
     NLR_HIP(hipMalloc(&p, bytes ? bytes : 16));
     m->allocs.push_back(p);
-    if (bytes) NLR_HIP(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, m->up));  // pageable source: staged before return
+    if (bytes) {  // the sources are temporaries of the caller: complete the copy before returning
+        NLR_HIP(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, m->up));
+        NLR_HIP(hipStreamSynchronize(m->up));
+    }
     *out = p;
     return NLR_OK;
 }
@@ -112,76 +115,58 @@ static Mat mat_from(const NlrLinear &l, uint32_t col0, uint32_t ncols) {
     return m;
 }
 
-// Fragment order is output-tile-major, [otile][kgroup] (the order nlr_gemm consumes them).
-// f32 fragments: [otile][kgroup][lane] float4; lane (i = lane&31, h = lane>>5), element e:
-//   row = 32*o + i, input feature = 8*g + 4*h + e    (k-step s = 4*(g&3)+e of input tile g>>2 reads accumulator
-//   register s, whose feature row for lane half h is (s&3) + 8*(s>>2) + 4*h = e + 8*(g&3) + 4*h)
-static std::vector<float> pack_f32(const Mat &w, uint32_t OT, uint32_t KG) {
-    std::vector<float> p((size_t)KG * OT * 64 * 4);
-    for (uint32_t o = 0; o < OT; ++o)
-        for (uint32_t g = 0; g < KG; ++g)
-            for (uint32_t lane = 0; lane < 64; ++lane)
-                for (uint32_t e = 0; e < 4; ++e)
-                    p[(((size_t)o * KG + g) * 64 + lane) * 4 + e] = w.get(32 * o + (lane & 31), 8 * g + 4 * (lane >> 5) + e);
-    return p;
-}
-
-// bf16 fragments: [otile][kstep][lane] 8 x bf16; element j of lane half h is input feature
-//   16*g + 8*(j>>2) + 4*h + (j&3)   (the k order of an accumulator tile reused as B operand)
-static std::vector<uint16_t> pack_bf16(const Mat &w, uint32_t OT, uint32_t KG) {
-    std::vector<uint16_t> p((size_t)KG * OT * 64 * 8);
-    for (uint32_t o = 0; o < OT; ++o)
-        for (uint32_t g = 0; g < KG; ++g)
-            for (uint32_t lane = 0; lane < 64; ++lane)
-                for (uint32_t j = 0; j < 8; ++j)
-                    p[(((size_t)o * KG + g) * 64 + lane) * 8 + j] =
-                        f32_to_bf16(w.get(32 * o + (lane & 31), 16 * g + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)));
-    return p;
-}
-
-// split-bf16 fragments: for every (kstep, otile) the hi fragment then the lo fragment (W = hi + lo)
-static std::vector<uint16_t> pack_x3(const Mat &w, uint32_t OT, uint32_t KG) {
-    std::vector<uint16_t> p((size_t)KG * OT * 2 * 64 * 8);
-    for (uint32_t o = 0; o < OT; ++o)
-        for (uint32_t g = 0; g < KG; ++g)
-            for (uint32_t lane = 0; lane < 64; ++lane)
-                for (uint32_t j = 0; j < 8; ++j) {
-                    const float v = w.get(32 * o + (lane & 31), 16 * g + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3));
-                    const uint16_t hi = f32_to_bf16(v);
-                    uint32_t hb = (uint32_t)hi << 16;
-                    float hf;
-                    memcpy(&hf, &hb, 4);
-                    const size_t base = (((size_t)o * KG + g) * 2) * 64 * 8;
-                    p[base + (size_t)lane * 8 + j] = hi;
-                    p[base + 64 * 8 + (size_t)lane * 8 + j] = f32_to_bf16(v - hf);
-                }
-    return p;
-}
-
-// The weight tape: GEMMs appended in the order nlr_mlp_kernel consumes them, each padded to whole chunks of NLR_TAPE_CHUNK bytes
-// (must equal NLR_CHUNK_FRAGS KiB in nlr_mlp.hip).
+// ---- weight fragments (layouts: nlr_mlp_kernel.h).  One fragment = 1 KiB = 64 lanes x 16 B, the A operand of one MFMA
+// step for 16 output rows; lane = (m = lane & 15, q = lane >> 4).
+//   bf16  (v_mfma_f32_16x16x32_bf16): rows 16R + m, k-block g (32 input features): element j = W[16R + m][32g + 16(j>>2) + 4q + (j&3)]
+//         - the k order in which two 16-row accumulator tiles of the previous layer, converted pairwise, form the B operand
+//   f32   (v_mfma_f32_16x16x4_f32, 4 k-steps per fragment): rows 16R + m, input row block J (16 features): element e = W[16R + m][16J + 4q + e]
+// GEMM order on the tape: output unit o (32 rows) -> k-group g -> row block j (R = 2o + j; RH = 1: R = o, only the first 16 rows
+// of the unit exist) [-> hi, lo fragment of the split-bf16 form].
 enum { TAPE_F32 = 0, TAPE_BF16 = 1, TAPE_X3 = 2 };
 #define NLR_TAPE_CHUNK 32768
 struct TapeBuilder {
     std::vector<uint8_t> bytes;
-    // even_chunks: pad to an even number of chunks (the view layers >= 2 sit in a runtime loop whose chunk parity
-    // must not change from one iteration to the next; see Tape::step in nlr_mlp.hip)
-    void add(const Mat &w, uint32_t out_pad, uint32_t in_pad, int kind, bool even_chunks = false) {
-        const size_t start = bytes.size();
-        const uint32_t OT = out_pad / 32;
-        if (kind == TAPE_F32) {
-            auto p = pack_f32(w, OT, in_pad / 8);
-            bytes.insert(bytes.end(), (const uint8_t *)p.data(), (const uint8_t *)(p.data() + p.size()));
-        } else if (kind == TAPE_BF16) {
-            auto p = pack_bf16(w, OT, (in_pad + 15) / 16);
-            bytes.insert(bytes.end(), (const uint8_t *)p.data(), (const uint8_t *)(p.data() + p.size()));
-        } else {
-            auto p = pack_x3(w, OT, (in_pad + 15) / 16);
-            bytes.insert(bytes.end(), (const uint8_t *)p.data(), (const uint8_t *)(p.data() + p.size()));
-        }
-        bytes.resize((bytes.size() + NLR_TAPE_CHUNK - 1) / NLR_TAPE_CHUNK * NLR_TAPE_CHUNK, 0);
-        if (even_chunks && (((bytes.size() - start) / NLR_TAPE_CHUNK) & 1)) bytes.resize(bytes.size() + NLR_TAPE_CHUNK, 0);
+    size_t frags() const { return bytes.size() / 1024; }
+    void frag_bf16(const Mat &w, uint32_t R, uint32_t g, bool lo_part) {
+        uint16_t f[64 * 8];
+        for (uint32_t lane = 0; lane < 64; ++lane)
+            for (uint32_t j = 0; j < 8; ++j) {
+                const float v = w.get(16 * R + (lane & 15), 32 * g + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3));
+                const uint16_t hi = f32_to_bf16(v);
+                if (!lo_part) {
+                    f[lane * 8 + j] = hi;
+                } else {  // W = hi + lo
+                    uint32_t hb = (uint32_t)hi << 16;
+                    float hf;
+                    memcpy(&hf, &hb, 4);
+                    f[lane * 8 + j] = f32_to_bf16(v - hf);
+                }
+            }
+        bytes.insert(bytes.end(), (const uint8_t *)f, (const uint8_t *)f + sizeof(f));
     }
+    void frag_f32(const Mat &w, uint32_t R, uint32_t J) {
+        float f[64 * 4];
+        for (uint32_t lane = 0; lane < 64; ++lane)
+            for (uint32_t e = 0; e < 4; ++e) f[lane * 4 + e] = w.get(16 * R + (lane & 15), 16 * J + 4 * (lane >> 4) + e);
+        bytes.insert(bytes.end(), (const uint8_t *)f, (const uint8_t *)f + sizeof(f));
+    }
+    // out_pad: rows padded to whole units of 32 (RH = 2) or to 16 (RH = 1, a single unit); in_pad: input features padded to 32
+    void add(const Mat &w, uint32_t out_pad, uint32_t in_pad, int kind, uint32_t RH = 2) {
+        const uint32_t OT = RH == 2 ? out_pad / 32 : 1;
+        const uint32_t KG = kind == TAPE_F32 ? in_pad / 16 : in_pad / 32;
+        for (uint32_t o = 0; o < OT; ++o)
+            for (uint32_t g = 0; g < KG; ++g)
+                for (uint32_t j = 0; j < RH; ++j) {
+                    const uint32_t R = RH == 2 ? 2 * o + j : o;
+                    if (kind == TAPE_F32) {
+                        frag_f32(w, R, g);
+                    } else {
+                        frag_bf16(w, R, g, false);
+                        if (kind == TAPE_X3) frag_bf16(w, R, g, true);
+                    }
+                }
+    }
+    void pad_to_chunk() { bytes.resize((bytes.size() + NLR_TAPE_CHUNK - 1) / NLR_TAPE_CHUNK * NLR_TAPE_CHUNK, 0); }
 };
 
 static int upload_bias(NlrModel *m, const float *b, uint32_t n, uint32_t pad, float **out) {
@@ -250,21 +235,23 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     lv.HT = (sem_layer ? 2 : 0) + (lv.use_int ? 2 : 0);
     NLR_CHECK_ARG(lv.K + (lv.use_int ? 1 : 0) <= 32, "class_num %u (+intensity) exceeds one 32-row output tile", lv.K);
 
-    const uint32_t Fpad = ((lv.F + 7) / 8) * 8;
     lv.prec = prec;
     const int crit = (prec == NLR_PREC_FAST) ? TAPE_X3 : TAPE_F32;   // density trunk + heads
     const int view = (prec == NLR_PREC_F32) ? TAPE_F32 : TAPE_BF16;  // view MLP
-    TapeBuilder tb;
-    std::vector<float> bias;  // b_d0 | b_d2 | b_h1 | b_h2 | view0 | view1 | view2.. | rgb, each padded to whole tiles
+    // The tile's program (nlr_mlp_kernel.h): bf16 view MLP: [T T V0 V1 V0 V1 | hidden.. | RGB] (the trunk + heads T and view
+    // layers 0/1 run once per 32-sample half); exact-f32 chain: [T V0 V1 | hidden.. | RGB], consumed once per half.
+    std::vector<float> bias;  // b_d0 | b_d2 | b_h1 | b_h2 | view0 | view1 | view2.. | rgb, each padded to whole units of 32
     auto push_bias = [&](const float *b, uint32_t n, uint32_t pad) {
         for (uint32_t i = 0; i < pad; ++i) bias.push_back(i < n ? b[i] : 0.0f);
     };
+    const uint32_t Fp32 = ((lv.F + 31) / 32) * 32;
+    TapeBuilder trunk;
     // density trunk
-    tb.add(mat_from(d.density0, 0, lv.F), 64, Fpad, crit);
+    trunk.add(mat_from(d.density0, 0, lv.F), 64, Fp32, crit);
     push_bias(d.density0.bias, 64, 64);
-    tb.add(mat_from(d.density2, 0, 64), lv.WB, 64, crit);
+    trunk.add(mat_from(d.density2, 0, 64), lv.WB, 64, crit);
     push_bias(d.density2.bias, lv.WB, lv.WB);
-    // heads: [sem0 ; int0] stacked, then a block-diagonal [sem2 | 0 ; 0 | int2] into one 32-row tile
+    // heads: [sem0 ; int0] stacked, then a block-diagonal [sem2 | 0 ; 0 | int2] into one 32-row unit
     if (lv.HT) {
         const uint32_t HH = lv.HT * 32;
         Mat h1(HH, lv.WB), h2(32, HH);
@@ -294,23 +281,35 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
             for (uint32_t c = 0; c < 64; ++c) h2.at(lv.int_row, r0 + c) = d.int2.weight[c];
             b2[lv.int_row] = d.int2.bias[0];
         }
-        tb.add(h1, HH, lv.WB, crit);
+        trunk.add(h1, HH, lv.WB, crit);
         push_bias(b1.data(), HH, HH);
-        tb.add(h2, 32, HH, crit);
+        trunk.add(h2, 32, HH, crit);
         push_bias(b2.data(), 32, 32);
     } else {
         push_bias(nullptr, 0, 32);  // keeps the block layout of the kernel (OB_H2 slot)
     }
     // view MLP.  Input of layer 0 = [bottleneck (WB) | dir_enc (E)]; of layer 1 = [x (W) | bottleneck | dir_enc]
-    // (models.py:1223-1228).  The E dir-encoding columns are zero-padded to one 32-feature tile.
+    // (models.py:1223-1228).  The E dir-encoding columns are zero-padded to one 32-feature k-block.
     const uint32_t in0 = lv.WB + lv.E, in1 = lv.W + in0;
     if ((rc = check_linear(d.view[0], lv.W, in0, "lin_second_stage_0"))) return rc;
     if ((rc = check_linear(d.view[1], lv.W, in1, "lin_second_stage_1"))) return rc;
     NLR_CHECK_ARG(lv.E <= 32, "deg_view %u gives %u > 32 direction features -- no fused path", lv.deg, lv.E);
-    tb.add(mat_from(d.view[0], 0, in0), lv.W, lv.WB + 32, view);
+    TapeBuilder v01;
+    v01.add(mat_from(d.view[0], 0, in0), lv.W, lv.WB + 32, view);
     push_bias(d.view[0].bias, lv.W, lv.W);
-    tb.add(mat_from(d.view[1], 0, in1), lv.W, lv.W + lv.WB + 32, view);
+    v01.add(mat_from(d.view[1], 0, in1), lv.W, lv.W + lv.WB + 32, view);
     push_bias(d.view[1].bias, lv.W, lv.W);
+    TapeBuilder tb;
+    auto append = [&](const TapeBuilder &x) { tb.bytes.insert(tb.bytes.end(), x.bytes.begin(), x.bytes.end()); };
+    if (prec == NLR_PREC_F32) {
+        append(trunk);
+        append(v01);
+    } else {
+        append(trunk);
+        append(trunk);
+        append(v01);
+        append(v01);
+    }
     for (uint32_t l = 2; l < lv.D; ++l) {
         char nm[64];
         snprintf(nm, sizeof(nm), "lin_second_stage_%u", l);
@@ -319,8 +318,9 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
         push_bias(d.view[l].bias, lv.W, lv.W);
     }
     if ((rc = check_linear(d.rgb_layer, 3, lv.W, "rgb_layer"))) return rc;
-    tb.add(mat_from(d.rgb_layer, 0, lv.W), 32, lv.W, view);
+    tb.add(mat_from(d.rgb_layer, 0, lv.W), 16, lv.W, view, 1);
     push_bias(d.rgb_layer.bias, 3, 32);
+    tb.pad_to_chunk();
     lv.bias_count = (uint32_t)bias.size();
     NLR_CHECK_ARG(lv.bias_count <= 4096, "bias block of %u floats exceeds the 4096-float LDS reservation", lv.bias_count);
     if ((rc = dev_upload(m, bias.data(), bias.size() * 4, (void **)&lv.bias_all))) return rc;

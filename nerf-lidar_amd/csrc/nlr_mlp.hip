@@ -42,12 +42,12 @@ int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uin
     NLR_CHECK_ARG(P.M > 0, "mlp: no samples");
     NLR_CHECK_ARG(P.tape && P.tape_chunks > 0, "mlp: weight tape missing");
     NLR_CHECK_ARG(P.bias_all && P.bias_count <= 4096 && P.bias_count % 4 == 0, "mlp: bias block missing or > 4096 floats");
-    const uint32_t FG = (P.F + 7) / 8;
-    // persistent workgroups: one per CU (112 KiB of LDS each, so one is all a CU holds), tiles of 128 samples round-robin
+    const uint32_t FT = (P.F + 31) / 32;
+    // persistent workgroups: one per CU (112 KiB of LDS each, so one is all a CU holds), tiles of 256 samples round-robin
     NLR_CHECK_ARG(cus > 0, "mlp: CU count of the model's device is unknown");
-    const uint32_t ntiles = (P.M + 127) / 128;
+    const uint32_t ntiles = (P.M + NLR_TILE - 1) / NLR_TILE;
     dim3 grid(ntiles < cus ? ntiles : cus);
-    if (WB == 256 && FG == 5) {
+    if (WB == 256 && FT == 2 && P.F % 4 == 0) {
 #define NLR_TRY(wt, ht, pr)                                   \
     if (W == wt * 32 && HT == ht && prec == pr) {             \
         NLR_MLP_LAUNCH_NAME(wt, ht, pr)(P, grid, st);         \
@@ -59,6 +59,6 @@ int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uin
     }
     NLR_FAIL(NLR_ERR_UNSUPPORTED,
              "NerfMLP shape (width %u, bottleneck %u, %u grid features, %u head tiles, precision %u) has no fused kernel "
-             "instance; built: (width 256, sem+intensity), (width 256, sem), (width 128, sem), bottleneck 256, 40 grid features",
+             "instance; built: (width 256, sem+intensity), (width 256, sem), (width 128, sem), bottleneck 256, 33..64 grid features",
              W, WB, P.F, HT, prec);
 }

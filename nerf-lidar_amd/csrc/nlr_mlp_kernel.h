@@ -7,45 +7,45 @@
 //   ZI/models.py:939-951, 1223-1234, 1251   lin_second_stage_i (+skip concat after layer 0), rgb_layer, sigmoid, padding
 //
 // Design (CDNA4, not a translation of the nn.Linear chain):
-//   * the whole chain runs TRANSPOSED, activations^T = W . x^T, so that an MFMA result tile (32 output
-//     features x 32 samples: sample on the lane, features in the 16 accumulator registers) is already
-//     the B operand of the next layer's MFMA (cdna_hip_programming.md section 3, "An accumulator tile as
-//     the next MFMA's operand").  Activations never leave the register file: no LDS round trip, no
-//     barrier between the 8+ layers.  One wavefront owns 32 samples end to end.
-//   * weights are the A operand, pre-packed at model-create time into exactly the per-lane fragment
-//     order (including the permuted k order the accumulator layout implies), so every fragment fetch is
-//     one fully coalesced 16-byte-per-lane load of 1 KiB per wavefront.
-//   * the 27 direction-encoding features are computed once per ray by a small pre-kernel and ride through view
-//     layers 0 and 1 as one extra zero-padded 32-feature input tile, so every GEMM has K % 32 == 0;
-//   * nothing but the weight tape is read from global memory after the prologue: all biases sit in LDS.
-//   * precision: layers whose error reaches depth / semantic argmax / intensity (density trunk, heads)
-//     use the exact-f32 MFMA (v_mfma_f32_32x32x2_f32); the view MLP (rgb only, 92 % of the MACs) uses
-//     bf16 MFMA (v_mfma_f32_32x32x16_bf16) with f32 accumulation.  NLR_PREC_F32 runs everything in f32.
+//   * the whole chain runs TRANSPOSED, activations^T = W . x^T, on v_mfma_f32_16x16x32_bf16: a result tile (16 output
+//     features x 16 samples) has the sample on the lane (col = lane & 15) and rows 4*(lane>>4) + r in its 4 registers, and
+//     two such tiles (32 consecutive output features) converted pairwise to bf16 ARE the B operand of the next layer's MFMA
+//     for that 32-feature k-block: lane (col, q) element j <-> feature 32*kb + 16*(j>>2) + 4*q + (j&3).  Activations never
+//     leave the register file: no LDS round trip, no barrier between the 8+ layers.
+//   * weights are the A operand, pre-packed at model-create time into exactly that per-lane order, one 1 KiB fragment per
+//     (16 output rows, 32-feature k-block), streamed L2 -> LDS by LDS-DMA through a 3 x 32 KiB ring shared by the 4 waves.
+//   * ONE WAVE OWNS 64 SAMPLES (4 column tiles) in the hidden layers: every fragment read from LDS feeds 4 MFMAs.  Round 1
+//     ran 32 samples per wave on v_mfma_f32_32x32x16_bf16 (1 MFMA per fragment): profiles/r02_mfma_shape*_microbench.txt
+//     put that structure's ceiling at 1.58 PFLOP/s (the chip holds 1.65-1.7 GHz under it) against 1.85 PFLOP/s at 2.13 GHz
+//     for 16x16x32 with 4 MFMAs per fragment; per fragment the LDS-DMA issue, the hand-shake and the ds_read are paid once.
+//   * the density trunk, the heads and view layers 0/1 (the skip layer, whose three operand sets would need ~400 registers at
+//     64 samples) run at HALF WIDTH (2 column tiles = 32 samples) once per half; their weights sit on the tape twice.
+//   * the 27 direction-encoding features are computed once per ray by a small pre-kernel and ride through view layers 0 and 1
+//     as one extra zero-padded 32-feature k-block, so every GEMM has K % 32 == 0;
+//   * nothing but the weight tape is read from global memory after the tile's input loads: all biases sit in LDS and enter
+//     as the C operand of each accumulator chain's first MFMA.
+//   * precision: NLR_PREC_FAST = trunk + heads in split-bf16 (W = Wh + Wl, x = xh + xl, three MFMAs: ~2^-16), view MLP bf16;
+//     NLR_PREC_MIXED = trunk + heads on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32); NLR_PREC_F32 = everything exact f32
+//     (the whole chain at half width, twice per tile).
 #pragma once
 #include "nlr_kernels.h"
 
 #include <type_traits>
 
-
-// row of accumulator register r for lane half h inside a 32-row tile
-__device__ __forceinline__ int nlr_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
 // ---- weight tape: global -> LDS by LDS-DMA (triple buffered), shared by the 4 waves of a workgroup ----------------
 // A chunk is 32 KiB = 32 fragments of 1 KiB (one fragment = the A operand of one MFMA for all 64 lanes).  Every
-// wave needs every fragment (each wave owns 32 samples and all output features), so staging through LDS cuts the
+// wave needs every fragment (each wave owns its samples and all output features), so staging through LDS cuts the
 // L2 -> CU weight traffic 4x against per-wave global loads and puts the fragment reads on ds_read_b128.
 // The refill is `global_load_lds_dwordx4` (one fragment = one wave-instruction, lane-linear in LDS, which is the
-// fragment layout): no VGPR staging and no ds_write pass.  Measured with in-kernel stamps, the
-// register-staged refill (8 global_load + 8 ds_write_b128 per wave per chunk) cost 38 % of the kernel: the
-// VGPR -> LDS store path moves ~79 B/clk/CU and does not overlap the fragment reads.
+// fragment layout): no VGPR staging and no ds_write pass.
 // Schedule inside chunk c (f = fragment position, all positions are compile-time after unrolling):
-//   f = 8   s_waitcnt vmcnt(0) (this wave's quarter of chunk c+1, requested at (16, c-1), has landed); signal
-//   f = 16  once all four waves have signalled, each wave requests its quarter (8 fragments) of chunk c+2 into LDS
-//           buffer (c+2)%3 = the buffer of chunk c-1 (hand-shake: see Tape::signal)
-//   every f: the fragment f+8 is requested into an 8-deep register ring right after fragment f is consumed; from
-//            f = 24 on these requests run into chunk c+1, so no LDS latency is exposed at a chunk boundary.
-// The last ds_read of chunk c-1 (issued at (23, c-1)) was waited for by the MFMA that consumed it at (7, c) and LDS
-// reads return in order, so at the signal every read of chunk c-1 by this wave is complete; the DMA is tracked by vmcnt.
+//   f = NLR_SIG_F   s_waitcnt vmcnt(0) (this wave's quarter of chunk c+1, requested at (NLR_POLL_F, c-1), has landed); signal
+//   f = NLR_POLL_F  once all four waves have signalled, each wave requests its quarter (8 fragments) of chunk c+2 into LDS
+//                   buffer (c+2)%3 = the buffer of chunk c-1 (hand-shake: see Tape::signal)
+//   every f: the fragment f+NLR_PF is requested into a register ring right after fragment f is consumed; near the end of a chunk
+//            these requests run into chunk c+1, so no LDS latency is exposed at a chunk boundary.
+// GEMMs follow each other on the tape without padding: a GEMM that starts at position F0 of a chunk simply continues the
+// position count (all GEMM sizes are compile-time); only the end of a tile's program is padded to a chunk boundary.
 #define NLR_CHUNK_FRAGS 32                       // fragments (1 KiB each) per chunk
 #define NLR_CHUNK_SLOTS (NLR_CHUNK_FRAGS * 64)   // uint4 slots per chunk
 #define NLR_NBUF 3
@@ -56,7 +56,7 @@ __device__ __forceinline__ int nlr_row(int r, int h) { return (r & 3) + 8 * (r >
 #define NLR_POLL_F 22
 #endif
 #ifndef NLR_PF
-#define NLR_PF 8                                 // fragment read-ahead (register ring)
+#define NLR_PF 8                                 // fragment read-ahead (register ring); must divide NLR_CHUNK_FRAGS
 #endif
 typedef const __attribute__((address_space(1))) void *nlr_gptr;
 typedef __attribute__((address_space(3))) void *nlr_lptr;
@@ -73,7 +73,7 @@ struct Tape {
     // this wave's quarter of chunk c: fragments 8w .. 8w+7, one LDS-DMA instruction each (LDS address = M0 + 16*lane).
     // Inline asm on purpose: behind the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the next ds_read (it cannot
     // tell the DMA's LDS target from the ring reads), which would expose the whole L2 latency once per chunk.  An asm
-    // DMA is invisible to hipcc's counters; `landed()` is the one wait that retires it.  M0 is saved and restored.
+    // DMA is invisible to hipcc's counters; `signal()` holds the one wait that retires it.  M0 is saved and restored.
     __device__ __forceinline__ void dma(int b) {  // tape chunk `nxt` -> LDS buffer b
         const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
         const uint64_t g = reinterpret_cast<uint64_t>(base) + (uint64_t)(uint32_t)nxt * (NLR_CHUNK_SLOTS * 16) + w * 8192u;
@@ -82,8 +82,7 @@ struct Tape {
         const uint32_t v = (uint32_t)lane * 16u;
         uint32_t keep;
         // The instruction offset advances the global AND the LDS address (LDS address = M0 + offset + 16 * lane), so four
-        // pieces share one M0 value and one SGPR base: 2 x (M0 write + 4 DMA instructions) instead of 8 x (M0 write,
-        // 64-bit scalar add, DMA) - the scalar bookkeeping, not the DMA itself, was most of a piece's issue cost.
+        // pieces share one M0 value and one SGPR base.
         asm volatile(
             "s_mov_b32 %[k], m0\n\t"
             "s_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
@@ -101,17 +100,14 @@ struct Tape {
             : [v] "v"(v), [l] "s"(l), [g0] "s"(g), [g4] "s"(g + 4096)
             : "memory", "scc");
     }
-    // Workgroup hand-shake without s_barrier.  A barrier per chunk cost 16 % of the kernel (stamps): the four
-    // waves drift by a few hundred cycles per chunk and a barrier makes every wave pay the maximum each time.  Instead:
-    //   (NLR_SIG_F, c)   own quarter of chunk c+1 has landed (vmcnt) and the last fragment of chunk c-1 is consumed
-    //                    -> lane 0 adds 1 to an LDS counter
+    // Workgroup hand-shake without s_barrier (a barrier per chunk charges every wave the slowest wave's drift each time):
+    //   (NLR_SIG_F, c)    own quarter of chunk c+1 has landed (vmcnt) and the last fragment of chunk c-1 is consumed
+    //                     -> lane 0 adds 1 to an LDS counter
     //   (NLR_POLL_F-2, c) the counter is read; (NLR_POLL_F, c) spin until it shows 4 (c+1): every wave is past its signal of
-    //                    chunk c, so chunk c+1 is complete (read from f = 24 on) and the buffer of chunk c-1 is free -> DMA c+2
-    // Waves may now drift by NLR_POLL_F - NLR_SIG_F fragment steps before anyone waits.  LDS accesses of one CU are
-    // served in order by one unit, so counter and data need no fence beyond the vmcnt wait in front of the signal.
-    // All three steps are single asm statements: any C++ control flow here splits the unrolled MFMA chain into basic
-    // blocks and the ds_read / MFMA interleave is lost.  hipcc does not count asm LDS operations; its own counted
-    // lgkmcnt waits only get more conservative by that (the counter retires in order).
+    //                     chunk c, so chunk c+1 is complete and the buffer of chunk c-1 is free -> DMA c+2
+    // LDS accesses of one CU are served in order by one unit, so counter and data need no fence beyond the vmcnt wait in
+    // front of the signal.  All three steps are single asm statements: C++ control flow here would split the unrolled
+    // MFMA chain into basic blocks and lose the ds_read / MFMA interleave.
     uint32_t *sig;
     uint32_t sig_addr, seen;
     __device__ __forceinline__ void signal() {
@@ -126,9 +122,6 @@ struct Tape {
             : [a] "v"(sig_addr), [one] "v"(1u)
             : "memory");
     }
-    // The counter is read by an ordinary (volatile, LDS address space) load: hipcc tracks it and puts the exact counted
-    // lgkmcnt in front of await()'s asm, whatever it did with the ring reads in between (in padding steps they are dead
-    // code, so a hand-counted wait would be wrong there).  Only the rare re-poll inside the spin drains the counter.
     __device__ __forceinline__ void peek() { seen = *reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t *>(sig_addr); }
     __device__ __forceinline__ void await() {
         const uint32_t target = 4u * (uint32_t)(cur + 1);
@@ -160,9 +153,9 @@ struct Tape {
         for (int f = 0; f < NLR_PF; ++f) ring[f] = buf(0)[f * 64 + lane];
     }
     // bookkeeping at fragment position F of the current chunk; returns the fragment (raw 16 bytes per lane).
-    // PAR (parity of the chunk index) is unused by the DMA refill; kept so that the GEMM drivers stay unchanged.
-    template <int F, int PAR>
+    template <int F>
     __device__ __forceinline__ uint4 step() {
+        static_assert(F >= 0 && F < NLR_CHUNK_FRAGS, "tape position");
         if constexpr (F == NLR_SIG_F) signal();
         if constexpr (F == NLR_POLL_F - 2) peek();
         if constexpr (F == NLR_POLL_F) {
@@ -189,204 +182,234 @@ __device__ __forceinline__ T nlr_as(const uint4 &v) {
 template <int I>
 using ic = std::integral_constant<int, I>;
 
-// number of 32-fragment chunks a GEMM occupies on the tape
-constexpr int nlr_nch(int ot, int kg, int fps) { return (ot * kg * fps + NLR_CHUNK_FRAGS - 1) / NLR_CHUNK_FRAGS; }
-
-// steps over the unused tail of a GEMM's last chunk (its bookkeeping positions must still run)
-template <int F, int PAR>
+// steps from position F to the next chunk boundary (bookkeeping positions must still run; the fragments are ignored)
+template <int F>
 __device__ __forceinline__ void nlr_pad(Tape &tp) {
-    if constexpr (F != 0) {
-        (void)tp.template step<F, PAR>();
-        nlr_pad<(F + 1) % NLR_CHUNK_FRAGS, PAR>(tp);
-    }
-}
-template <int F, int PAR>
-__device__ __forceinline__ void nlr_pad_chunk(Tape &tp) {  // one whole padding chunk
-    (void)tp.template step<F, PAR>();
-    if constexpr (F + 1 < NLR_CHUNK_FRAGS) nlr_pad_chunk<F + 1, PAR>(tp);
-}
-
-// Output-tile-major GEMM driver: for each 32-row output tile o, run all KG k-steps into ONE accumulator, then
-// hand the finished tile to `epi`.  Only two accumulator tiles are live (current + the one being post-processed),
-// and the epilogue of tile o-1 (ReLU / bf16 conversion / hi-lo split: ~80 VALU instructions) sits in the
-// instruction stream right behind the first MFMA of tile o, so it executes in the shadow of tile o's MFMA chain
-// instead of serialising between layers (the kernel runs one wave per SIMD: nothing else would hide it).
-//   FPS = fragments per k-step (1; 2 for the hi/lo pairs of the split-bf16 path); PAR0 = parity of the first chunk
-//   init(ic<o>) -> f32x16 bias tile;  step(acc&, ic<g>, frag0, frag1);  epi(ic<o>, acc)
-// epilogue pieces of one finished tile, from piece P0 up to NP (exclusive)
-template <int O, int P0, int NP, class Epi>
-__device__ __forceinline__ void nlr_epi_rest(const Epi &epi, const f32x16 &acc) {
-    if constexpr (P0 < NP) {
-        epi(ic<O>{}, ic<P0>{}, acc);
-        nlr_epi_rest<O, P0 + 1, NP>(epi, acc);
-    }
-}
-// NPP > 0: `pend(ic<p>)`, p < NPP, are the epilogue pieces of the PREVIOUS GEMM's last output tile; they run in the
-//          MFMA shadow of this GEMM's first output tile (whose first k-steps must not read that tile: true for the
-//          view layers, where k-step g reads input tile g/2 and the pending tile is the last one).
-// DEFER:   the last output tile of this GEMM is handed back raw in `last` (its epilogue becomes the next GEMM's `pend`)
-//          instead of being post-processed serially behind the last MFMA, where nothing would hide it.
-template <int OT, int KG, int FPS, int NP, int NPP, bool DEFER, int PAR0, int IDX, class Init, class Step, class Epi, class Pend>
-__device__ __forceinline__ void nlr_run(Tape &tp, f32x16 &prev, f32x16 &cur, f32x16 &nxt, f32x16 &last, const Init &init,
-                                        const Step &step, const Epi &epi, const Pend &pend) {
-    // Schedule inside one output tile of KG k-steps (all compile time):
-    //   steps D .. D+NP-1 : one piece each of the PREVIOUS tile's epilogue (D = 3 lets that tile's last MFMA retire first)
-    //   step  IG          : bias rows of the NEXT tile are read from LDS, a few steps before its first MFMA needs them
-    constexpr int D = (KG >= NP + 3) ? 3 : 0;
-    constexpr int IG = (KG >= NP + D + 4) ? KG - 4 : KG - 1;
-    static_assert(NPP == 0 || KG >= NPP + 3, "pending epilogue needs a long enough first tile");
-    if constexpr (IDX < OT * KG) {
-        constexpr int o = IDX / KG, g = IDX % KG;
-        if constexpr (g == 0) {
-            if constexpr (o > 0) {
-                prev = cur;
-                cur = nxt;
-            } else {
-                cur = init(ic<0>{});
-            }
-        }
-        constexpr int P0 = (IDX * FPS) % NLR_CHUNK_FRAGS;
-        constexpr int PAR = (PAR0 + (IDX * FPS) / NLR_CHUNK_FRAGS) & 1;
-        const uint4 f0 = tp.template step<P0, PAR>();
-        uint4 f1 = f0;
-        if constexpr (FPS == 2) f1 = tp.template step<P0 + 1, PAR>();
-        step(cur, ic<g>{}, f0, f1);
-        if constexpr (o > 0) {
-            if constexpr (g >= D && g - D < NP && g < KG - 1) epi(ic<o - 1>{}, ic<g - D>{}, prev);
-            if constexpr (g == KG - 1) nlr_epi_rest<o - 1, (KG - 1 - D < NP ? (KG - 1 - D > 0 ? KG - 1 - D : 0) : NP), NP>(epi, prev);
-        } else if constexpr (NPP > 0) {
-            if constexpr (g >= 3 && g - 3 < NPP) pend(ic<g - 3>{});
-        }
-        if constexpr (g == IG && o + 1 < OT) nxt = init(ic<o + 1>{});
-        // pin the issue order (fragment read-ahead, MFMA, epilogue piece): left alone, the scheduler sinks the
-        // ds_reads next to their use and every MFMA waits out the LDS latency
+    if constexpr (F % NLR_CHUNK_FRAGS != 0) {
+        (void)tp.template step<F % NLR_CHUNK_FRAGS>();
         __builtin_amdgcn_sched_barrier(0);
-        nlr_run<OT, KG, FPS, NP, NPP, DEFER, PAR0, IDX + 1>(tp, prev, cur, nxt, last, init, step, epi, pend);
-    } else {
-        if constexpr (DEFER) last = cur;
-        else nlr_epi_rest<OT - 1, 0, NP>(epi, cur);
-        nlr_pad<(OT * KG * FPS) % NLR_CHUNK_FRAGS, (PAR0 + nlr_nch(OT, KG, FPS) - 1) & 1>(tp);
+        nlr_pad<F % NLR_CHUNK_FRAGS + 1>(tp);
     }
-}
-// EVEN (unused since the LDS-DMA refill, kept for experiments): one padding chunk after a GEMM with an odd chunk count
-// NP: number of epilogue pieces per output tile
-template <int OT, int KG, int FPS, int NP, int PAR0, bool EVEN = false, class Init, class Step, class Epi>
-__device__ __forceinline__ void nlr_gemm(Tape &tp, const Init &init, const Step &step, const Epi &epi) {
-    f32x16 prev, cur, nxt, last;
-    nlr_run<OT, KG, FPS, NP, 0, false, PAR0, 0>(tp, prev, cur, nxt, last, init, step, epi, [](auto) {});
-    if constexpr (EVEN && (nlr_nch(OT, KG, FPS) & 1)) nlr_pad_chunk<0, (PAR0 + nlr_nch(OT, KG, FPS)) & 1>(tp);
-}
-// software-pipelined across GEMMs (see nlr_run): pend = previous GEMM's deferred tile, last = this GEMM's
-template <int OT, int KG, int NP, int NPP, bool DEFER, int PAR0, bool EVEN = false, class Init, class Step, class Epi, class Pend>
-__device__ __forceinline__ void nlr_gemm_pipe(Tape &tp, f32x16 &last, const Init &init, const Step &step, const Epi &epi, const Pend &pend) {
-    f32x16 prev, cur, nxt;
-    nlr_run<OT, KG, 1, NP, NPP, DEFER, PAR0, 0>(tp, prev, cur, nxt, last, init, step, epi, pend);
-    if constexpr (EVEN && (nlr_nch(OT, KG, 1) & 1)) nlr_pad_chunk<0, (PAR0 + nlr_nch(OT, KG, 1)) & 1>(tp);
 }
 
-__device__ __forceinline__ f32x16 nlr_bias_tile(const float *bias, int o, int h) {
-    f32x16 a;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(bias + o * 32 + 8 * q + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[q * 4 + e] = v[e];
-    }
-    return a;
-}
-
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-// ReLU is applied AFTER the conversion, on the packed pairs: a negative bf16 is a negative int16, so one
-// v_pk_max_i16 against zero clears two values (half the VALU work of v_max_f32 per value; -0.0 -> +0.0).
-template <bool RELU>
-__device__ __forceinline__ void nlr_pack1(TileH &dst, const f32x16 &src) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (__bf16)src[8 * s + j];
-        if (RELU) {
-            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            v = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
-        }
-        dst.f[s] = v;
-    }
-}
-// piece P (0..7) of the pack: values 2P, 2P+1 -> one packed dword of the tile
+// ---- register tiles ---------------------------------------------------------------------------------------------------
+// N = 16-sample column tiles held by the wave (4 = 64 samples, 2 = 32 samples: half width).
+// Unit: 32 output rows x 16N samples of f32 accumulators: a[jb][n][r] on lane (col, rb) is row 16*jb + 4*rb + r of column
+//       tile n, sample 16*n + col.
+// BT:   32 input features x 16N samples as MFMA B operands: n[t] element j on lane (col, q) is feature 16*(j>>2) + 4*q + (j&3).
+//       pack(Unit) -> BT is lane-local: BT.n[t][4*jb + r] = bf16(Unit.a[jb][t][r]).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <bool RELU, int P>
-__device__ __forceinline__ void nlr_pack_piece(TileH &dst, const f32x16 &src) {
-    const f32x2 x = {src[2 * P], src[2 * P + 1]};
+template <int N>
+struct BT {
+    bf16x8 n[N];
+};
+template <int N>
+struct Unit {
+    f32x4 a[2][N];
+};
+
+// epilogue piece P of 4N: column tile P >> 2, row block (P >> 1) & 1, register pair P & 1 -> one packed dword
+// ReLU is applied AFTER the conversion, on the packed pair: a negative bf16 is a negative int16, so one v_pk_max_i16
+// against zero clears two values (-0.0 -> +0.0).
+// OFF: the half-width GEMMs (N = 2) address column tiles OFF .. OFF+N-1 of a full-width BT<ND>
+template <bool RELU, int P, int OFF, int N, int ND>
+__device__ __forceinline__ void nlr_pack_piece(BT<ND> &dst, const Unit<N> &src) {
+    constexpr int n = P >> 2, jb = (P >> 1) & 1, pr = P & 1;
+    const f32x2 x = {src.a[jb][n][2 * pr], src.a[jb][n][2 * pr + 1]};
     bf16x2 v = __builtin_convertvector(x, bf16x2);  // one v_cvt_pk_bf16_f32 (RNE)
     if (RELU) {
-        const s16x2 z = {0, 0};  // max(bf16 bits as i16, 0): relu on the packed pair, -0 and negatives -> +0
+        const s16x2 z = {0, 0};
         v = __builtin_bit_cast(bf16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
     }
-    dst.f[P >> 2][2 * (P & 3)] = v[0];
-    dst.f[P >> 2][2 * (P & 3) + 1] = v[1];
+    dst.n[OFF + n][4 * jb + 2 * pr] = v[0];
+    dst.n[OFF + n][4 * jb + 2 * pr + 1] = v[1];
 }
 // hi = bf16(x), lo = bf16(x - hi)   (x - hi is exact in f32)
-template <bool RELU>
-__device__ __forceinline__ void nlr_split1(TileH &hi, TileH &lo, const f32x16 &src) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = src[8 * s + j];
-            if (RELU) v = fmaxf(v, 0.0f);
-            const __bf16 hh = (__bf16)v;
-            hi.f[s][j] = hh;
-            lo.f[s][j] = (__bf16)(v - (float)hh);
-        }
-}
-template <bool RELU, int P>
-__device__ __forceinline__ void nlr_split_piece(TileH &hi, TileH &lo, const f32x16 &src) {
-    f32x2 x = {src[2 * P], src[2 * P + 1]};
+template <bool RELU, int P, int OFF, int N, int ND>
+__device__ __forceinline__ void nlr_split_piece(BT<ND> &hi, BT<ND> &lo, const Unit<N> &src) {
+    constexpr int n = P >> 2, jb = (P >> 1) & 1, pr = P & 1;
+    f32x2 x = {src.a[jb][n][2 * pr], src.a[jb][n][2 * pr + 1]};
     if (RELU) x = __builtin_elementwise_max(x, (f32x2){0.0f, 0.0f});
     const bf16x2 h = __builtin_convertvector(x, bf16x2);
     const bf16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), bf16x2);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        hi.f[P >> 2][2 * (P & 3) + e] = h[e];
-        lo.f[P >> 2][2 * (P & 3) + e] = l[e];
+        hi.n[OFF + n][4 * jb + 2 * pr + e] = h[e];
+        lo.n[OFF + n][4 * jb + 2 * pr + e] = l[e];
     }
 }
-template <bool RELU>
-__device__ __forceinline__ f32x16 nlr_act(const f32x16 &src) {
-    f32x16 r = src;
+template <bool RELU, int OFF, int N, int ND, int P = 0>
+__device__ __forceinline__ void nlr_pack_all(BT<ND> &dst, const Unit<N> &src) {
+    if constexpr (P < 4 * N) {
+        nlr_pack_piece<RELU, P, OFF>(dst, src);
+        nlr_pack_all<RELU, OFF, N, ND, P + 1>(dst, src);
+    }
+}
+template <bool RELU, int OFF, int N, int ND, int P = 0>
+__device__ __forceinline__ void nlr_split_all(BT<ND> &hi, BT<ND> &lo, const Unit<N> &src) {
+    if constexpr (P < 4 * N) {
+        nlr_split_piece<RELU, P, OFF>(hi, lo, src);
+        nlr_split_all<RELU, OFF, N, ND, P + 1>(hi, lo, src);
+    }
+}
+template <bool RELU, int N>
+__device__ __forceinline__ void nlr_act_unit(Unit<N> &u) {
     if (RELU) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) r[i] = fmaxf(r[i], 0.0f);
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int n = 0; n < N; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u.a[jb][n][r] = fmaxf(u.a[jb][n][r], 0.0f);
     }
-    return r;
 }
 
-// MFMA steps ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void nlr_mma_bf16(f32x16 &acc, const uint4 &a, const bf16x8 &b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nlr_as<bf16x8>(a), b, acc, 0, 0, 0);
+// ---- MFMA steps: one tape fragment (16 output rows) against every column tile of the wave ---------------------------------
+// FIRST: the accumulator chain starts here, C = the bias rows of this row block
+template <bool FIRST, int OFF, int N, int ND>
+__device__ __forceinline__ void nlr_mma_bf16(f32x4 (&acc)[N], const f32x4 &bias, const uint4 &a, const BT<ND> &b) {
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nlr_as<bf16x8>(a), b.n[OFF + n], FIRST ? bias : acc[n], 0, 0, 0);
 }
 // Split-bf16 ("bf16x3"): W = Wh + Wl, x = xh + xl (each part bf16), W.x ~= Wh.xh + Wh.xl + Wl.xh with f32
 // accumulation: 16 mantissa bits per operand (relative error ~2^-16) at 3/16 of the exact-f32 MFMA cost.
-__device__ __forceinline__ void nlr_mma_x3(f32x16 &acc, const uint4 &ah, const uint4 &al, const bf16x8 &bh, const bf16x8 &bl) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nlr_as<bf16x8>(ah), bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nlr_as<bf16x8>(ah), bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nlr_as<bf16x8>(al), bh, acc, 0, 0, 0);
+template <bool FIRST, int OFF, int N, int ND>
+__device__ __forceinline__ void nlr_mma_x3(f32x4 (&acc)[N], const f32x4 &bias, const uint4 &ah, const uint4 &al, const BT<ND> &bh,
+                                           const BT<ND> &bl) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nlr_as<bf16x8>(ah), bh.n[OFF + n], FIRST ? bias : acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nlr_as<bf16x8>(ah), bl.n[OFF + n], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nlr_as<bf16x8>(al), bh.n[OFF + n], acc[n], 0, 0, 0);
+    }
 }
-// exact-f32 MFMA: one fragment (float4 per lane) carries 4 k-steps of 2 features
-template <int G, int KT>
-__device__ __forceinline__ void nlr_mma_f32(f32x16 &acc, const uint4 &a, const f32x16 (&in)[KT]) {
+// exact-f32 MFMA (v_mfma_f32_16x16x4_f32): one fragment (float4 per lane) carries the 4 k-steps of one 16-feature input row
+// block: element e of lane (m, q) is W[row m][16*J + 4*q + e], and register e of the input accumulator tile is exactly that
+// feature on lane (col, q).
+template <bool FIRST, int N>
+__device__ __forceinline__ void nlr_mma_f32(f32x4 (&acc)[N], const f32x4 &bias, const uint4 &a, const f32x4 (&in)[N]) {
     const f32x4 af = nlr_as<f32x4>(a);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], in[G >> 2][(G & 3) * 4 + e], acc, 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], in[n][e], (FIRST && e == 0) ? bias : acc[n], 0, 0, 0);
 }
 
-// WT = view width / 32, BT = bottleneck / 32, FG = ceil(F/8), HT = head hidden tiles (0, 2 or 4)
+// sum / max over the 4 lanes (col, q = 0..3) that hold the rows of one sample: v_permlane16_swap exchanges the odd 16-lane
+// rows of its first operand with the even rows of its second (given one value twice it returns [row0,row0,row2,row2] and
+// [row1,row1,row3,row3]), v_permlane32_swap does the same with 32-lane halves: two VALU exchanges, no LDS traffic.
+__device__ __forceinline__ float nlr_q_sum(float v) {
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (uint32_t)a[0]) + __builtin_bit_cast(float, (uint32_t)a[1]);
+    u = __builtin_bit_cast(uint32_t, v);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (uint32_t)b[0]) + __builtin_bit_cast(float, (uint32_t)b[1]);
+}
+__device__ __forceinline__ float nlr_q_max(float v) {
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (uint32_t)a[0]), __builtin_bit_cast(float, (uint32_t)a[1]));
+    u = __builtin_bit_cast(uint32_t, v);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)b[0]), __builtin_bit_cast(float, (uint32_t)b[1]));
+}
+
+// ---- GEMM driver ---------------------------------------------------------------------------------------------------------
+// One GEMM = OT output units (32 rows; RH = 2 row blocks of 16, or RH = 1: only the first 16 rows exist) x KG k-groups
+// (32 input features per group on the bf16 paths, 16 on the exact-f32 path), N column tiles.  Tape order: unit-major, then
+// k-group, then row block: step (o, g, j) consumes FPS fragments (2 = the hi / lo pair of the split-bf16 path) and issues
+// N (3N, 4N) MFMAs.  One accumulator unit runs all its steps; the finished unit's epilogue (bf16 pack + ReLU, or hi/lo split)
+// is cut into NP pieces issued behind the next unit's MFMAs, the next unit's bias rows are read from LDS a few steps early,
+// and the issue order is pinned with sched_barrier(0) per step (left alone, hipcc sinks the ring's ds_reads next to their
+// use and every MFMA waits out the LDS latency).
+//   F0     tape position (fragments since a chunk boundary) at which this GEMM starts
+//   NPP    > 0: `pend(ic<p>)`, p < NPP, are the epilogue pieces of the PREVIOUS GEMM's last unit; they run behind the MFMAs of
+//          this GEMM's first steps and are complete before step PBY (the first step that reads that unit)
+//   DEFER  the last unit of this GEMM is handed back raw in `last` (its epilogue becomes the next GEMM's `pend`) instead of
+//          being post-processed serially behind the last MFMA, where nothing would hide it
+//   bias(ic<o>, f32x4 (&b)[2]);  mma(unit&, ic<g>, ic<j>, f0, f1, biasrow);  epi(ic<o>, ic<p>, unit);  pend(ic<p>);  bg(ic<step>)
+constexpr int nlr_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+template <int O, int P0, int P1, class Epi, int N>
+__device__ __forceinline__ void nlr_pieces(const Epi &epi, const Unit<N> &u) {
+    if constexpr (P0 < P1) {
+        epi(ic<O>{}, ic<P0>{}, u);
+        nlr_pieces<O, P0 + 1, P1>(epi, u);
+    }
+}
+template <int P0, int P1, class Pend>
+__device__ __forceinline__ void nlr_pend(const Pend &pend) {
+    if constexpr (P0 < P1) {
+        pend(ic<P0>{});
+        nlr_pend<P0 + 1, P1>(pend);
+    }
+}
+
+template <int OT, int KG, int RH, int N, int FPS, int F0, int NP, int NPP, int PBY, bool DEFER, int IDX, class Bias, class Mma, class Epi,
+          class Pend, class Bg>
+__device__ __forceinline__ void nlr_run(Tape &tp, Unit<N> &prev, Unit<N> &cur, f32x4 (&bcur)[2], f32x4 (&bnxt)[2], Unit<N> &last,
+                                        const Bias &bias, const Mma &mma, const Epi &epi, const Pend &pend, const Bg &bg) {
+    constexpr int SPU = KG * RH;                      // steps per unit
+    constexpr int D = SPU > 1 ? 1 : 0;                // the previous unit's last MFMAs retire during step 0
+    constexpr int PPS = nlr_ceil_div(NP, SPU - D);    // epilogue pieces per step
+    constexpr int IG = SPU >= 4 ? SPU - 3 : SPU - 1;  // step at which the next unit's bias rows are requested
+    if constexpr (IDX < OT * SPU) {
+        constexpr int o = IDX / SPU, s = IDX % SPU, g = s / RH, j = s % RH;
+        if constexpr (s == 0) {
+            if constexpr (o > 0) {
+                prev = cur;
+                bcur[0] = bnxt[0];
+                bcur[1] = bnxt[1];
+            } else {
+                bias(ic<0>{}, bcur);
+            }
+        }
+        constexpr int P0 = (F0 + IDX * FPS) % NLR_CHUNK_FRAGS;
+        const uint4 f0 = tp.template step<P0>();
+        uint4 f1 = f0;
+        if constexpr (FPS == 2) f1 = tp.template step<(P0 + 1) % NLR_CHUNK_FRAGS>();
+        mma(cur, ic<g>{}, ic<j>{}, f0, f1, bcur[j]);
+        if constexpr (o > 0) {
+            if constexpr (s >= D && (s - D) * PPS < NP)
+                nlr_pieces<o - 1, (s - D) * PPS, ((s - D + 1) * PPS < NP ? (s - D + 1) * PPS : NP)>(epi, prev);
+        } else if constexpr (NPP > 0) {
+            constexpr int PP = nlr_ceil_div(NPP, PBY - D);
+            if constexpr (s >= D && (s - D) * PP < NPP) nlr_pend<(s - D) * PP, ((s - D + 1) * PP < NPP ? (s - D + 1) * PP : NPP)>(pend);
+        }
+        if constexpr (s == IG && o + 1 < OT) bias(ic<o + 1>{}, bnxt);
+        bg(ic<IDX>{});
+        __builtin_amdgcn_sched_barrier(0);
+        nlr_run<OT, KG, RH, N, FPS, F0, NP, NPP, PBY, DEFER, IDX + 1>(tp, prev, cur, bcur, bnxt, last, bias, mma, epi, pend, bg);
+    } else {
+        if constexpr (DEFER) last = cur;
+        else nlr_pieces<OT - 1, 0, NP>(epi, cur);
+    }
+}
+// plain form: no pending pieces, no background work, serial epilogue of the last unit
+template <int OT, int KG, int RH, int N, int FPS, int F0, int NP, class Bias, class Mma, class Epi>
+__device__ __forceinline__ void nlr_gemm(Tape &tp, const Bias &bias, const Mma &mma, const Epi &epi) {
+    Unit<N> prev, cur, last;
+    f32x4 bc[2], bn[2];
+    nlr_run<OT, KG, RH, N, FPS, F0, NP, 0, 1, false, 0>(tp, prev, cur, bc, bn, last, bias, mma, epi, [](auto) {}, [](auto) {});
+}
+// software-pipelined across GEMMs: pend = the previous GEMM's deferred unit, last = this GEMM's (when DEFER)
+template <int OT, int KG, int RH, int N, int F0, int NP, int NPP, int PBY, bool DEFER, class Bias, class Mma, class Epi, class Pend>
+__device__ __forceinline__ void nlr_gemm_pipe(Tape &tp, Unit<N> &last, const Bias &bias, const Mma &mma, const Epi &epi, const Pend &pend) {
+    Unit<N> prev, cur;
+    f32x4 bc[2], bn[2];
+    nlr_run<OT, KG, RH, N, 1, F0, NP, NPP, PBY, DEFER, 0>(tp, prev, cur, bc, bn, last, bias, mma, epi, pend, [](auto) {});
+}
+
+// WT = view width / 32, BW = bottleneck / 32, FT = ceil(F / 32) grid-feature k-blocks, HT = head hidden units of 32 (0, 2 or 4)
 // PREC: NLR_PREC_F32 (all f32), NLR_PREC_MIXED (trunk+heads f32, view bf16), NLR_PREC_FAST (trunk+heads bf16x3, view bf16)
 #define NLR_BIAS_MAX 4096  // floats of LDS reserved for the bias block (16 KiB)
-template <int WT, int BT, int FG, int HT, int PREC>
+#define NLR_TILE 256       // samples per workgroup tile: 4 waves x 64
+template <int WT, int BW, int FT, int HT, int PREC>
 __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     __shared__ __align__(16) uint4 lds_tape[NLR_NBUF * NLR_CHUNK_SLOTS];
     __shared__ __align__(16) float lds_bias[NLR_BIAS_MAX];
@@ -394,48 +417,27 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     constexpr bool VIEW_F32 = (PREC == NLR_PREC_F32);
     constexpr bool X3 = (PREC == NLR_PREC_FAST);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 31, h = lane >> 5;
-    constexpr int FT = (FG + 3) / 4;
+    const int col = lane & 15, q = lane >> 4;
     constexpr int HTA = HT > 0 ? HT : 1;
     // bias block offsets (floats)
-    constexpr int OB_D0 = 0, OB_D2 = 64, OB_H1 = OB_D2 + BT * 32, OB_H2 = OB_H1 + HT * 32, OB_V0 = OB_H2 + 32;
+    constexpr int OB_D0 = 0, OB_D2 = 64, OB_H1 = OB_D2 + BW * 32, OB_H2 = OB_H1 + HT * 32, OB_V0 = OB_H2 + 32;
     constexpr int OB_V1 = OB_V0 + WT * 32, OB_VL = OB_V1 + WT * 32;
-    // chunk parity at the start of every GEMM of the fixed sequence (see Tape::step)
-    constexpr int CF = X3 ? 2 : 1;                     // fragments per k-step in the trunk/heads
-    constexpr int KU = X3 ? 2 : 4;                     // k-steps per 32-feature input tile in the trunk/heads
-    constexpr int KV = VIEW_F32 ? 4 : 2;               // ... in the view MLP
-    constexpr int KD0 = X3 ? (FG + 1) / 2 : FG;
-    constexpr int P_D0 = 0;
-    constexpr int P_D2 = P_D0 + nlr_nch(2, KD0, CF);
-    constexpr int P_H1 = P_D2 + nlr_nch(BT, 2 * KU, CF);
-    constexpr int P_H2 = P_H1 + (HT > 0 ? nlr_nch(HT, BT * KU, CF) : 0);
-    constexpr int P_V0 = P_H2 + (HT > 0 ? nlr_nch(1, HT * KU, CF) : 0);
-    constexpr int P_V1 = P_V0 + nlr_nch(WT, (BT + 1) * KV, 1);
-    constexpr int P_VL = P_V1 + nlr_nch(WT, (WT + BT + 1) * KV, 1);
+    // ---- the tile's program on the tape (fragments; must match build_level in nlr_api.hip)
+    constexpr int TF = X3 ? 2 : 1;                        // fragments per step in the trunk / heads
+    constexpr int TK = X3 ? 1 : 2;                        // k-groups per 32 input features in the trunk / heads
+    constexpr int VK = VIEW_F32 ? 2 : 1;                  // ... in the view MLP
+    constexpr int FR_D0 = 2 * (FT * TK) * 2 * TF, FR_D2 = BW * (2 * TK) * 2 * TF;
+    constexpr int FR_H1 = HT * (BW * TK) * 2 * TF, FR_H2 = HT > 0 ? (HT * TK) * 2 * TF : 0;
+    constexpr int FR_T = FR_D0 + FR_D2 + FR_H1 + FR_H2;   // trunk + heads, one half
+    constexpr int FR_V0 = WT * ((BW + 1) * VK) * 2, FR_V1 = WT * ((WT + BW + 1) * VK) * 2;
+    constexpr int FR_HL = WT * (WT * VK) * 2, FR_RGB = (WT * VK);
+    static_assert(FR_HL % NLR_CHUNK_FRAGS == 0, "hidden view layers must cover whole chunks (width 128 or 256)");
+    // bf16 view MLP: [T T V0 V1 V0 V1 | hidden x (depth-2) | RGB];  f32 view MLP: [T V0 V1 | hidden | RGB] once per half
+    constexpr int F_VIEW = VIEW_F32 ? FR_T : 2 * FR_T;
+    constexpr int F_HID = VIEW_F32 ? FR_T + FR_V0 + FR_V1 : 2 * (FR_T + FR_V0 + FR_V1);
+    constexpr int F_END = F_HID + FR_RGB;                 // (+ hidden layers: whole chunks)
 
-    // ---- persistent workgroup: one per CU, tiles (4 waves x 32 samples) taken round-robin.  The bias block is staged
-    // once, the weight tape streams round and round (its read-ahead runs across the tile seam into chunk 0 of the next
-    // tile), and the next tile's inputs are requested as soon as this tile's are unpacked: no prologue, dispatch gap or
-    // exposed load latency between tiles.
-    const uint32_t ntiles = (P.M + 127) / 128;
-    auto load_inputs = [&](uint32_t tile, f32x4 (&fv)[FG], f32x4 (&ev)[4]) {
-        const uint32_t smp = (tile * 4 + wave) * 32 + col;
-        const uint32_t sc = smp < P.M ? smp : P.M - 1;
-        const float *fp = P.feat + (size_t)sc * P.F;
-#pragma unroll
-        for (int g = 0; g < FG; ++g) {
-            const uint32_t f0 = 8 * g + 4 * h;
-            fv[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (f0 + 4 <= P.F)
-                fv[g] = P.feat_piece_major ? *reinterpret_cast<const f32x4 *>(P.feat + ((size_t)(f0 >> 2) * P.M + sc) * 4)
-                                           : *reinterpret_cast<const f32x4 *>(fp + f0);
-        }
-        const uint32_t ray = sc / P.S;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ev[q] = *reinterpret_cast<const f32x4 *>(P.enc + (size_t)ray * 32 + 8 * q + 4 * h);
-    };
-    f32x4 fv[FG], ev[4];
-    load_inputs(blockIdx.x, fv, ev);
+    const uint32_t ntiles = (P.M + NLR_TILE - 1) / NLR_TILE;
     for (uint32_t i = threadIdx.x * 4; i < P.bias_count; i += 1024)
         *reinterpret_cast<f32x4 *>(lds_bias + i) = *reinterpret_cast<const f32x4 *>(P.bias_all + i);
 
@@ -444,263 +446,454 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     tp.lds = lds_tape;
     tp.sig = &lds_sig;
     tp.sig_addr = (uint32_t)(uintptr_t)(nlr_lptr)&lds_sig;
-    tp.total = P.rgb ? (int)P.tape_chunks : P_V0;  // without the view MLP a tile consumes the trunk + head chunks only
+    // without the view MLP a tile consumes the trunk + head fragments only (padded to whole chunks)
+    tp.total = P.rgb ? (int)P.tape_chunks : nlr_ceil_div(F_VIEW, NLR_CHUNK_FRAGS);
     tp.tid = threadIdx.x;
     tp.lane = lane;
     tp.prologue();  // ends with __syncthreads(): the bias block is visible too
 
+    auto nop = [](auto) {};
+    auto bias_rows = [&](const float *b, f32x4 (&out)[2]) {  // rows 4q..4q+3 of both 16-row blocks of a unit
+        out[0] = *reinterpret_cast<const f32x4 *>(b + 4 * q);
+        out[1] = *reinterpret_cast<const f32x4 *>(b + 16 + 4 * q);
+    };
+
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint32_t sample = (tile * 4 + wave) * 32 + col;
-    const bool valid = sample < P.M;
-    // ---- features / direction encoding -> accumulator-layout tiles (lane half h holds rows 8q+4h..+3 of each group)
-    f32x16 fin[FT];
+    const uint32_t base = tile * NLR_TILE + wave * 64;
+    // ---- inputs of the wave's 64 samples: grid features as f32 units (row block J = 2t + jb holds features 16J + 4q + r),
+    // direction encoding of the sample's ray as one more 32-feature unit
+    Unit<2> fin[2][FT], encu[2];
 #pragma unroll
-    for (int t = 0; t < FT; ++t)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fin[t][r] = 0.0f;
+        for (int n = 0; n < 2; ++n) {
+            const uint32_t smp = base + (2 * h + n) * 16 + col;
+            const uint32_t sc = smp < P.M ? smp : P.M - 1;
 #pragma unroll
-    for (int g = 0; g < FG; ++g)
+            for (int t = 0; t < FT; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) fin[g >> 2][(g & 3) * 4 + e] = fv[g][e];
-    f32x16 encf;
+                for (int jb = 0; jb < 2; ++jb) {
+                    const uint32_t piece = 8 * t + 4 * jb + q;  // float4 index inside the feature row
+                    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (4 * piece + 4 <= P.F)
+                        v = P.feat_piece_major ? *reinterpret_cast<const f32x4 *>(P.feat + ((size_t)piece * P.M + sc) * 4)
+                                               : *reinterpret_cast<const f32x4 *>(P.feat + (size_t)sc * P.F + 4 * piece);
+                    fin[h][t].a[jb][n] = v;
+                }
+            const uint32_t ray = sc / P.S;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) encf[q * 4 + e] = ev[q][e];
-    if (tile + gridDim.x < ntiles) load_inputs(tile + gridDim.x, fv, ev);
-
-    float raw_density = 0.0f;
-    f32x16 lo;  // [K logits | intensity] output tile of the heads
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lo[r] = 0.0f;
-    TileH hbe[VIEW_F32 ? 1 : BT + 1];      // bf16 [bottleneck | dir-enc] tiles for the view MLP
-    f32x16 hbf[VIEW_F32 ? BT + 1 : 1];     // the same in f32 (NLR_PREC_F32)
-
-    if constexpr (X3) {
-        // ---- density trunk + heads on split-bf16
-        constexpr int FK = (FG + 1) / 2;  // 16-feature k-steps covering the grid features
-        TileH fh[FT], fl[FT];
-#pragma unroll
-        for (int t = 0; t < FT; ++t) nlr_split1<false>(fh[t], fl[t], fin[t]);
-        TileH dh[2], dl[2];
-        nlr_gemm<2, FK, 2, 8, P_D0 & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D0, o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
-                constexpr int G = decltype(g)::value;
-                nlr_mma_x3(a, f0, f1, fh[G >> 1].f[G & 1], fl[G >> 1].f[G & 1]);
-            },
-            [&](auto o, auto p, const f32x16 &a) { nlr_split_piece<true, decltype(p)::value>(dh[decltype(o)::value], dl[decltype(o)::value], a); });
-        TileH hbl[BT];
-        nlr_gemm<BT, 4, 2, 8, P_D2 & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D2, o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
-                constexpr int G = decltype(g)::value;
-                nlr_mma_x3(a, f0, f1, dh[G >> 1].f[G & 1], dl[G >> 1].f[G & 1]);
-            },
-            [&](auto o, auto p, const f32x16 &a) {
-                constexpr int O = decltype(o)::value, Pc = decltype(p)::value;
-                if constexpr (O == 0 && Pc == 0) raw_density = a[0];
-                nlr_split_piece<false, Pc>(hbe[O], hbl[O], a);
-            });
-        if constexpr (HT > 0) {
-            TileH qh[HTA], ql[HTA];
-            nlr_gemm<HT, BT * 2, 2, 8, P_H1 & 1>(
-                tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H1, o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
-                    constexpr int G = decltype(g)::value;
-                    nlr_mma_x3(a, f0, f1, hbe[G >> 1].f[G & 1], hbl[G >> 1].f[G & 1]);
-                },
-                [&](auto o, auto p, const f32x16 &a) { nlr_split_piece<true, decltype(p)::value>(qh[decltype(o)::value], ql[decltype(o)::value], a); });
-            nlr_gemm<1, HT * 2, 2, 1, P_H2 & 1>(
-                tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H2, o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &f1) {
-                    constexpr int G = decltype(g)::value;
-                    nlr_mma_x3(a, f0, f1, qh[G >> 1].f[G & 1], ql[G >> 1].f[G & 1]);
-                },
-                [&](auto, auto, const f32x16 &a) { lo = a; });
+            for (int jb = 0; jb < 2; ++jb)
+                encu[h].a[jb][n] = P.rgb ? *reinterpret_cast<const f32x4 *>(P.enc + (size_t)ray * 32 + 16 * jb + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
-    } else {
-        // ---- density trunk + heads on the exact-f32 MFMA
-        f32x16 hid[2];
-        nlr_gemm<2, FG, 1, 1, P_D0 & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D0, o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, FT>(a, f0, fin); },
-            [&](auto o, auto, const f32x16 &a) { hid[decltype(o)::value] = nlr_act<true>(a); });
-        f32x16 hb[BT];
-        nlr_gemm<BT, 8, 1, 1, P_D2 & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_D2, o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, 2>(a, f0, hid); },
-            [&](auto o, auto, const f32x16 &a) {
-                constexpr int O = decltype(o)::value;
-                if constexpr (O == 0) raw_density = a[0];
-                hb[O] = a;
-                if constexpr (VIEW_F32) hbf[O] = a; else nlr_pack1<false>(hbe[O], a);
-            });
-        if constexpr (HT > 0) {
-            f32x16 hh[HTA];
-            nlr_gemm<HT, BT * 4, 1, 1, P_H1 & 1>(
-                tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H1, o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, BT>(a, f0, hb); },
-                [&](auto o, auto, const f32x16 &a) { hh[decltype(o)::value] = nlr_act<true>(a); });
-            nlr_gemm<1, HT * 4, 1, 1, P_H2 & 1>(
-                tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_H2, o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, HTA>(a, f0, hh); },
-                [&](auto, auto, const f32x16 &a) { lo = a; });
-        }
-    }
-    if (h == 0 && valid) {
-        const float x = raw_density + P.density_bias;
-        P.density[sample] = x > 20.0f ? x : log1pf(expf(x));
-    }
-    // ---- semantic / intensity outputs: rows [0,K) logits -> softmax, row int_row -> intensity.
-    // Per-sample heads are stored class-major ([K, M], [3, M]): one store instruction writes two 128-byte runs.
-    if constexpr (HT > 0) {
-        if (P.K > 0) {  // softmax over rows [0,K) of this column, split over the two lane halves
-            // Branch-free: rows >= K take -inf (exp -> 0), so the only exec-masked instructions are the stores; a
-            // per-row `if (row < K)` differs between the lane halves and costs an exec save/restore per row.
-            float e[16], mx = -INFINITY, s = 0.0f;
+
+    // per-sample outputs of one half: density, class probabilities, intensity (class-major / channel-major stores: the 16
+    // lanes of a row write 64 consecutive bytes)
+    auto heads_out = [&](auto hh, const float (&raw)[2], const Unit<2> &lo) {
+        constexpr int h = decltype(hh)::value;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                e[r] = nlr_row(r, h) < (int)P.K ? lo[r] : -INFINITY;
-                mx = fmaxf(mx, e[r]);
+        for (int n = 0; n < 2; ++n) {
+            const uint32_t smp = base + (2 * h + n) * 16 + col;
+            const bool valid = smp < P.M;
+            if (q == 0 && valid) {
+                const float x = raw[n] + P.density_bias;
+                P.density[smp] = x > 20.0f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20), models.py:1116
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if constexpr (HT > 0) {
+                if (P.K > 0) {  // softmax over rows [0,K): 8 rows in this lane, the rest in the 3 other lanes of the column
+                    float e[2][4], mx = -INFINITY, s = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                e[r] = expf(e[r] - mx);
-                s += e[r];
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            e[jb][r] = (16 * jb + 4 * q + r) < (int)P.K ? lo.a[jb][n][r] : -INFINITY;
+                            mx = fmaxf(mx, e[jb][r]);
+                        }
+                    mx = nlr_q_max(mx);
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            e[jb][r] = expf(e[jb][r] - mx);
+                            s += e[jb][r];
+                        }
+                    s = nlr_q_sum(s);
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * jb + 4 * q + r;
+                            if (valid && row < (int)P.K) P.sem[(size_t)row * P.M + smp] = e[jb][r] / s;
+                        }
+                }
+                if (P.inten && valid) {
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * jb + 4 * q + r == (int)P.int_row) P.inten[smp] = lo.a[jb][n][r];
+                }
             }
-            s += __shfl_xor(s, 32, 64);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (valid && nlr_row(r, h) < (int)P.K) P.sem[(size_t)nlr_row(r, h) * P.M + sample] = e[r] / s;
         }
-        if (P.inten && valid) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (nlr_row(r, h) == (int)P.int_row) P.inten[sample] = lo[r];
-        }
-    }
-    if (P.rgb == nullptr) continue;  // density/semantic/intensity only (uniform for the whole grid)
+    };
 
-    // ---- view MLP.  Layer 0 input = [bottleneck | enc]; layer 1 input = [x | bottleneck | enc] (skip concat,
-    // models.py:1227-1228); the 27 dir-encoding features ride as one extra zero-padded 32-feature input tile.
-    f32x16 out1;
     if constexpr (!VIEW_F32) {
-        nlr_pack1<false>(hbe[BT], encf);
-        TileH x[WT], y[WT];
-        // The last output tile of every layer is carried raw (`cx` / `cy`) and packed in the MFMA shadow of the next
-        // layer's first tile: x/y[WT-1] is read last there (k-steps 2 WT - 2, 2 WT - 1), so nothing waits for it.
-        // Needs 2 WT - 2 > 6 k-steps ahead of the first read of that tile: WT >= 6; narrower layers run the serial form.
-        constexpr bool PIPE = WT >= 6;
-        constexpr int NPP = PIPE ? 8 : 0;
-        f32x16 cx, cy;
-        nlr_gemm_pipe<WT, (BT + 1) * 2, 8, 0, PIPE, P_V0 & 1>(
-            tp, cx, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V0, o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
-                constexpr int G = decltype(g)::value;
-                nlr_mma_bf16(a, f0, hbe[G >> 1].f[G & 1]);
-            },
-            [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); }, [](auto) {});
-        nlr_gemm_pipe<WT, (WT + BT + 1) * 2, 8, NPP, PIPE, P_V1 & 1>(
-            tp, cy, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V1, o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
-                constexpr int G = decltype(g)::value;
-                if constexpr (G < 2 * WT) nlr_mma_bf16(a, f0, x[G >> 1].f[G & 1]);
-                else nlr_mma_bf16(a, f0, hbe[(G - 2 * WT) >> 1].f[G & 1]);
-            },
-            [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(y[decltype(o)::value], a); },
-            [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(x[WT - 1], cx); });
-        // hidden layers 2..D-1, two per iteration (y -> x -> y) so that no tile copies are needed
+        // =================================================== bf16 view MLP ===================================================
+        BT<4> hbe[BW + 1];  // [bottleneck | dir-enc] k-blocks of both halves (column tiles 2h, 2h+1 belong to half h)
+        auto trunk = [&](auto hh) {
+            constexpr int h = decltype(hh)::value;
+            constexpr int F0 = h * FR_T;
+            float raw[2] = {0.0f, 0.0f};
+            Unit<2> lo;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) lo.a[jb][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (X3) {
+                // ---- density trunk + heads on split-bf16
+                BT<2> fh[FT], fl[FT];
+#pragma unroll
+                for (int t = 0; t < FT; ++t) nlr_split_all<false, 0>(fh[t], fl[t], fin[h][t]);
+                BT<2> dh[2], dl[2];
+                nlr_gemm<2, FT, 2, 2, 2, F0, 8>(
+                    tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D0 + 32 * decltype(o)::value, b); },
+                    [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &f1, const f32x4 &bj) {
+                        constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                        nlr_mma_x3<G == 0, 0>(u.a[J], bj, f0, f1, fh[G], fl[G]);
+                    },
+                    [&](auto o, auto p, const Unit<2> &u) { nlr_split_piece<true, decltype(p)::value, 0>(dh[decltype(o)::value], dl[decltype(o)::value], u); });
+                BT<2> hbl[BW];
+                nlr_gemm<BW, 2, 2, 2, 2, F0 + FR_D0, 8>(
+                    tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D2 + 32 * decltype(o)::value, b); },
+                    [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &f1, const f32x4 &bj) {
+                        constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                        nlr_mma_x3<G == 0, 0>(u.a[J], bj, f0, f1, dh[G], dl[G]);
+                    },
+                    [&](auto o, auto p, const Unit<2> &u) {
+                        constexpr int O = decltype(o)::value, Pc = decltype(p)::value;
+                        if constexpr (O == 0 && Pc == 0) {
+                            raw[0] = u.a[0][0][0];
+                            raw[1] = u.a[0][1][0];
+                        }
+                        // hi part straight into the view MLP's operand (column tiles of this half), lo part local
+                        constexpr int n = Pc >> 2, jb = (Pc >> 1) & 1, pr = Pc & 1;
+                        const f32x2 xv = {u.a[jb][n][2 * pr], u.a[jb][n][2 * pr + 1]};
+                        const bf16x2 hv = __builtin_convertvector(xv, bf16x2);
+                        const bf16x2 lv = __builtin_convertvector(xv - __builtin_convertvector(hv, f32x2), bf16x2);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            hbe[O].n[2 * h + n][4 * jb + 2 * pr + e] = hv[e];
+                            hbl[O].n[n][4 * jb + 2 * pr + e] = lv[e];
+                        }
+                    });
+                if constexpr (HT > 0) {
+                    BT<2> qh[HTA], ql[HTA];
+                    nlr_gemm<HT, BW, 2, 2, 2, F0 + FR_D0 + FR_D2, 8>(
+                        tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_H1 + 32 * decltype(o)::value, b); },
+                        [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &f1, const f32x4 &bj) {
+                            constexpr int G = decltype(g)::value, J = decltype(j)::value;
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) {
+                                u.a[J][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nlr_as<bf16x8>(f0), hbe[G].n[2 * h + n], G == 0 ? bj : u.a[J][n], 0, 0, 0);
+                                u.a[J][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nlr_as<bf16x8>(f0), hbl[G].n[n], u.a[J][n], 0, 0, 0);
+                                u.a[J][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nlr_as<bf16x8>(f1), hbe[G].n[2 * h + n], u.a[J][n], 0, 0, 0);
+                            }
+                        },
+                        [&](auto o, auto p, const Unit<2> &u) { nlr_split_piece<true, decltype(p)::value, 0>(qh[decltype(o)::value], ql[decltype(o)::value], u); });
+                    nlr_gemm<1, HT, 2, 2, 2, F0 + FR_D0 + FR_D2 + FR_H1, 1>(
+                        tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_H2, b); },
+                        [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &f1, const f32x4 &bj) {
+                            constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                            nlr_mma_x3<G == 0, 0>(u.a[J], bj, f0, f1, qh[G], ql[G]);
+                        },
+                        [&](auto, auto, const Unit<2> &u) { lo = u; });
+                }
+            } else {
+                // ---- density trunk + heads on the exact-f32 MFMA (k-groups of 16 features)
+                Unit<2> hid[2];
+                nlr_gemm<2, 2 * FT, 2, 2, 1, F0, 1>(
+                    tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D0 + 32 * decltype(o)::value, b); },
+                    [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                        constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                        nlr_mma_f32<G == 0>(u.a[J], bj, f0, fin[h][G >> 1].a[G & 1]);
+                    },
+                    [&](auto o, auto, const Unit<2> &u) {
+                        hid[decltype(o)::value] = u;
+                        nlr_act_unit<true>(hid[decltype(o)::value]);
+                    });
+                Unit<2> hb[BW];
+                nlr_gemm<BW, 4, 2, 2, 1, F0 + FR_D0, 1>(
+                    tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D2 + 32 * decltype(o)::value, b); },
+                    [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                        constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                        nlr_mma_f32<G == 0>(u.a[J], bj, f0, hid[G >> 1].a[G & 1]);
+                    },
+                    [&](auto o, auto, const Unit<2> &u) {
+                        constexpr int O = decltype(o)::value;
+                        if constexpr (O == 0) {
+                            raw[0] = u.a[0][0][0];
+                            raw[1] = u.a[0][1][0];
+                        }
+                        hb[O] = u;
+                        nlr_pack_all<false, 2 * h>(hbe[O], u);
+                    });
+                if constexpr (HT > 0) {
+                    Unit<2> hq[HTA];
+                    nlr_gemm<HT, 2 * BW, 2, 2, 1, F0 + FR_D0 + FR_D2, 1>(
+                        tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_H1 + 32 * decltype(o)::value, b); },
+                        [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                            constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                            nlr_mma_f32<G == 0>(u.a[J], bj, f0, hb[G >> 1].a[G & 1]);
+                        },
+                        [&](auto o, auto, const Unit<2> &u) {
+                            hq[decltype(o)::value] = u;
+                            nlr_act_unit<true>(hq[decltype(o)::value]);
+                        });
+                    nlr_gemm<1, 2 * HT, 2, 2, 1, F0 + FR_D0 + FR_D2 + FR_H1, 1>(
+                        tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_H2, b); },
+                        [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                            constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                            nlr_mma_f32<G == 0>(u.a[J], bj, f0, hq[G >> 1].a[G & 1]);
+                        },
+                        [&](auto, auto, const Unit<2> &u) { lo = u; });
+                }
+            }
+            heads_out(hh, raw, lo);
+        };
+        trunk(ic<0>{});
+        trunk(ic<1>{});
+        if (P.rgb == nullptr) {  // density / semantic / intensity only (uniform for the whole grid)
+            nlr_pad<F_VIEW % NLR_CHUNK_FRAGS>(tp);
+            continue;
+        }
+        // ---- view MLP.  Layer 0 input = [bottleneck | enc]; layer 1 input = [x | bottleneck | enc] (skip concat,
+        // models.py:1227-1228); the 27 dir-encoding features ride as one extra zero-padded 32-feature k-block.
+        nlr_pack_all<false, 0>(hbe[BW], encu[0]);
+        nlr_pack_all<false, 2>(hbe[BW], encu[1]);
+        BT<4> x[WT], y[WT];
+        Unit<2> cyh[2];
+        // The last output unit of every layer is carried raw and packed behind the MFMAs of the next layer's first unit, whose
+        // first k-groups do not read it.
+        auto view01 = [&](auto hh) {
+            constexpr int h = decltype(hh)::value;
+            constexpr int F0 = F_VIEW + h * (FR_V0 + FR_V1);
+            Unit<2> cx;
+            nlr_gemm_pipe<WT, BW + 1, 2, 2, F0, 8, 0, 1, true>(
+                tp, cx, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_V0 + 32 * decltype(o)::value, b); },
+                [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    nlr_mma_bf16<G == 0, 2 * h>(u.a[J], bj, f0, hbe[G]);
+                },
+                [&](auto o, auto p, const Unit<2> &u) { nlr_pack_piece<true, decltype(p)::value, 2 * h>(x[decltype(o)::value], u); }, nop);
+            nlr_gemm_pipe<WT, WT + BW + 1, 2, 2, F0 + FR_V0, 8, 8, (WT - 1) * 2, true>(
+                tp, cyh[h], [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_V1 + 32 * decltype(o)::value, b); },
+                [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    if constexpr (G < WT) nlr_mma_bf16<G == 0, 2 * h>(u.a[J], bj, f0, x[G]);
+                    else nlr_mma_bf16<false, 2 * h>(u.a[J], bj, f0, hbe[G - WT]);
+                },
+                [&](auto o, auto p, const Unit<2> &u) { nlr_pack_piece<true, decltype(p)::value, 2 * h>(y[decltype(o)::value], u); },
+                [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 2 * h>(x[WT - 1], cx); });
+        };
+        view01(ic<0>{});
+        view01(ic<1>{});
+        // hidden layers 2..depth-1 at full width (4 MFMAs per tape fragment), two per iteration (y -> x -> y) so that no
+        // tile copies are needed.  The pending last unit of layer 1 is the concatenation of the two halves' units.
+        Unit<4> cx4, cy4;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                cy4.a[jb][n] = cyh[0].a[jb][n];
+                cy4.a[jb][2 + n] = cyh[1].a[jb][n];
+            }
         uint32_t l = 2;
         for (; l + 1 < P.depth; l += 2) {
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm_pipe<WT, WT * 2, 8, NPP, PIPE, P_VL & 1>(
-                tp, cx, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
-                    constexpr int G = decltype(g)::value;
-                    nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
+            nlr_gemm_pipe<WT, WT, 2, 4, F_HID, 16, 16, (WT - 1) * 2, true>(
+                tp, cx4, [&](auto o, f32x4(&b)[2]) { bias_rows(bl + 32 * decltype(o)::value, b); },
+                [&](Unit<4> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    nlr_mma_bf16<G == 0, 0>(u.a[J], bj, f0, y[G]);
                 },
-                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); },
-                [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(y[WT - 1], cy); });
-            nlr_gemm_pipe<WT, WT * 2, 8, NPP, PIPE, P_VL & 1>(
-                tp, cy, [&](auto o) { return nlr_bias_tile(bl + WT * 32, o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
-                    constexpr int G = decltype(g)::value;
-                    nlr_mma_bf16(a, f0, x[G >> 1].f[G & 1]);
+                [&](auto o, auto p, const Unit<4> &u) { nlr_pack_piece<true, decltype(p)::value, 0>(x[decltype(o)::value], u); },
+                [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 0>(y[WT - 1], cy4); });
+            nlr_gemm_pipe<WT, WT, 2, 4, F_HID, 16, 16, (WT - 1) * 2, true>(
+                tp, cy4, [&](auto o, f32x4(&b)[2]) { bias_rows(bl + WT * 32 + 32 * decltype(o)::value, b); },
+                [&](Unit<4> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    nlr_mma_bf16<G == 0, 0>(u.a[J], bj, f0, x[G]);
                 },
-                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(y[decltype(o)::value], a); },
-                [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(x[WT - 1], cx); });
-        }
-        if (l < P.depth) {  // odd number of hidden layers: one more, result moved back into y
-            const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm_pipe<WT, WT * 2, 8, NPP, false, P_VL & 1>(
-                tp, cx, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
-                    constexpr int G = decltype(g)::value;
-                    nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
-                },
-                [&](auto o, auto p, const f32x16 &a) { nlr_pack_piece<true, decltype(p)::value>(x[decltype(o)::value], a); },
-                [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(y[WT - 1], cy); });
-#pragma unroll
-            for (int t = 0; t < WT; ++t) y[t] = x[t];
-            cy = cx;  // not pending any more: y[WT-1] is complete (the flag below is compile-time, see `odd`)
+                [&](auto o, auto p, const Unit<4> &u) { nlr_pack_piece<true, decltype(p)::value, 0>(y[decltype(o)::value], u); },
+                [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 0>(x[WT - 1], cx4); });
         }
         const bool odd = ((P.depth - 2) & 1) != 0;
-        if (odd) {
-            nlr_gemm_pipe<1, WT * 2, 1, 0, false, P_VL & 1>(
-                tp, cx, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
-                    constexpr int G = decltype(g)::value;
-                    nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
-                },
-                [&](auto, auto, const f32x16 &a) { out1 = a; }, [](auto) {});
-        } else {
-            nlr_gemm_pipe<1, WT * 2, 1, NPP, false, P_VL & 1>(
-                tp, cx, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
-                    constexpr int G = decltype(g)::value;
-                    nlr_mma_bf16(a, f0, y[G >> 1].f[G & 1]);
-                },
-                [&](auto, auto, const f32x16 &a) { out1 = a; },
-                [&](auto p) { nlr_pack_piece<true, decltype(p)::value>(y[WT - 1], cy); });
-        }
-    } else {
-        hbf[BT] = encf;
-        f32x16 x[WT], y[WT];
-        nlr_gemm<WT, (BT + 1) * 4, 1, 1, P_V0 & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V0, o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, BT + 1>(a, f0, hbf); },
-            [&](auto o, auto, const f32x16 &a) { x[decltype(o)::value] = nlr_act<true>(a); });
-        nlr_gemm<WT, (WT + BT + 1) * 4, 1, 1, P_V1 & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_V1, o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) {
-                constexpr int G = decltype(g)::value;
-                if constexpr (G < 4 * WT) nlr_mma_f32<G, WT>(a, f0, x);
-                else nlr_mma_f32<G - 4 * WT, BT + 1>(a, f0, hbf);
-            },
-            [&](auto o, auto, const f32x16 &a) { y[decltype(o)::value] = nlr_act<true>(a); });
-        for (uint32_t l = 2; l < P.depth; ++l) {
+        if (odd) {  // odd number of hidden layers: one more, serial epilogue, result moved back into y
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
-            nlr_gemm<WT, WT * 4, 1, 1, P_VL & 1>(
-                tp, [&](auto o) { return nlr_bias_tile(bl, o.value, h); },
-                [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, WT>(a, f0, y); },
-                [&](auto o, auto, const f32x16 &a) { x[decltype(o)::value] = nlr_act<true>(a); });
+            nlr_gemm_pipe<WT, WT, 2, 4, F_HID, 16, 16, (WT - 1) * 2, false>(
+                tp, cx4, [&](auto o, f32x4(&b)[2]) { bias_rows(bl + 32 * decltype(o)::value, b); },
+                [&](Unit<4> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    nlr_mma_bf16<G == 0, 0>(u.a[J], bj, f0, y[G]);
+                },
+                [&](auto o, auto p, const Unit<4> &u) { nlr_pack_piece<true, decltype(p)::value, 0>(x[decltype(o)::value], u); },
+                [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 0>(y[WT - 1], cy4); });
 #pragma unroll
             for (int t = 0; t < WT; ++t) y[t] = x[t];
         }
-        nlr_gemm<1, WT * 4, 1, 1, P_VL & 1>(
-            tp, [&](auto o) { return nlr_bias_tile(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), o.value, h); },
-            [&](f32x16 &a, auto g, const uint4 &f0, const uint4 &) { nlr_mma_f32<decltype(g)::value, WT>(a, f0, y); },
-            [&](auto, auto, const f32x16 &a) { out1 = a; });
-    }
-    if (h == 0 && valid) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float z = P.rgb_premul * out1[c] + P.rgb_bias;
-            const float sg = 1.0f / (1.0f + expf(-z));
-            P.rgb[(size_t)c * P.M + sample] = sg * (1.0f + 2.0f * P.rgb_padding) - P.rgb_padding;
+        Unit<4> out1;
+        const float *brgb = lds_bias + OB_VL + (P.depth - 2) * (WT * 32);
+        auto rgb_mma = [&](Unit<4> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+            constexpr int G = decltype(g)::value, J = decltype(j)::value;
+            nlr_mma_bf16<G == 0, 0>(u.a[J], bj, f0, y[G]);
+        };
+        if (odd) {
+            nlr_gemm_pipe<1, WT, 1, 4, F_HID, 1, 0, 1, false>(
+                tp, cx4, [&](auto, f32x4(&b)[2]) { bias_rows(brgb, b); }, rgb_mma, [&](auto, auto, const Unit<4> &u) { out1 = u; }, nop);
+        } else {
+            nlr_gemm_pipe<1, WT, 1, 4, F_HID, 1, 16, WT - 1, false>(
+                tp, cx4, [&](auto, f32x4(&b)[2]) { bias_rows(brgb, b); }, rgb_mma, [&](auto, auto, const Unit<4> &u) { out1 = u; },
+                [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 0>(y[WT - 1], cy4); });
         }
+        if (q == 0) {  // rows 0..2 of the output unit sit on lanes 0..15
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const uint32_t smp = base + n * 16 + col;
+                if (smp < P.M) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float z = P.rgb_premul * out1.a[0][n][c] + P.rgb_bias;
+                        const float sg = 1.0f / (1.0f + expf(-z));
+                        P.rgb[(size_t)c * P.M + smp] = sg * (1.0f + 2.0f * P.rgb_padding) - P.rgb_padding;
+                    }
+                }
+            }
+        }
+        nlr_pad<F_END % NLR_CHUNK_FRAGS>(tp);
+    } else {
+        // =================================================== exact-f32 chain: each half runs the whole tape ======================
+        auto pass = [&](auto hh) {
+            constexpr int h = decltype(hh)::value;
+            float raw[2] = {0.0f, 0.0f};
+            Unit<2> lo;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) lo.a[jb][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            Unit<2> hid[2];
+            nlr_gemm<2, 2 * FT, 2, 2, 1, 0, 1>(
+                tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D0 + 32 * decltype(o)::value, b); },
+                [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    nlr_mma_f32<G == 0>(u.a[J], bj, f0, fin[h][G >> 1].a[G & 1]);
+                },
+                [&](auto o, auto, const Unit<2> &u) {
+                    hid[decltype(o)::value] = u;
+                    nlr_act_unit<true>(hid[decltype(o)::value]);
+                });
+            Unit<2> hb[BW + 1];  // [bottleneck | dir-enc]
+            nlr_gemm<BW, 4, 2, 2, 1, FR_D0, 1>(
+                tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D2 + 32 * decltype(o)::value, b); },
+                [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    nlr_mma_f32<G == 0>(u.a[J], bj, f0, hid[G >> 1].a[G & 1]);
+                },
+                [&](auto o, auto, const Unit<2> &u) {
+                    constexpr int O = decltype(o)::value;
+                    if constexpr (O == 0) {
+                        raw[0] = u.a[0][0][0];
+                        raw[1] = u.a[0][1][0];
+                    }
+                    hb[O] = u;
+                });
+            if constexpr (HT > 0) {
+                Unit<2> hq[HTA];
+                nlr_gemm<HT, 2 * BW, 2, 2, 1, FR_D0 + FR_D2, 1>(
+                    tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_H1 + 32 * decltype(o)::value, b); },
+                    [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                        constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                        nlr_mma_f32<G == 0>(u.a[J], bj, f0, hb[G >> 1].a[G & 1]);
+                    },
+                    [&](auto o, auto, const Unit<2> &u) {
+                        hq[decltype(o)::value] = u;
+                        nlr_act_unit<true>(hq[decltype(o)::value]);
+                    });
+                nlr_gemm<1, 2 * HT, 2, 2, 1, FR_D0 + FR_D2 + FR_H1, 1>(
+                    tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_H2, b); },
+                    [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                        constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                        nlr_mma_f32<G == 0>(u.a[J], bj, f0, hq[G >> 1].a[G & 1]);
+                    },
+                    [&](auto, auto, const Unit<2> &u) { lo = u; });
+            }
+            heads_out(hh, raw, lo);
+            if (P.rgb == nullptr) {
+                nlr_pad<FR_T % NLR_CHUNK_FRAGS>(tp);
+                return;
+            }
+            hb[BW] = encu[h];
+            Unit<2> x[WT], y[WT];
+            nlr_gemm<WT, 2 * (BW + 1), 2, 2, 1, FR_T, 1>(
+                tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_V0 + 32 * decltype(o)::value, b); },
+                [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    nlr_mma_f32<G == 0>(u.a[J], bj, f0, hb[G >> 1].a[G & 1]);
+                },
+                [&](auto o, auto, const Unit<2> &u) {
+                    x[decltype(o)::value] = u;
+                    nlr_act_unit<true>(x[decltype(o)::value]);
+                });
+            nlr_gemm<WT, 2 * (WT + BW + 1), 2, 2, 1, FR_T + FR_V0, 1>(
+                tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_V1 + 32 * decltype(o)::value, b); },
+                [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    if constexpr (G < 2 * WT) nlr_mma_f32<G == 0>(u.a[J], bj, f0, x[G >> 1].a[G & 1]);
+                    else nlr_mma_f32<false>(u.a[J], bj, f0, hb[(G - 2 * WT) >> 1].a[G & 1]);
+                },
+                [&](auto o, auto, const Unit<2> &u) {
+                    y[decltype(o)::value] = u;
+                    nlr_act_unit<true>(y[decltype(o)::value]);
+                });
+            for (uint32_t l = 2; l < P.depth; ++l) {
+                const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
+                nlr_gemm<WT, 2 * WT, 2, 2, 1, F_HID, 1>(
+                    tp, [&](auto o, f32x4(&b)[2]) { bias_rows(bl + 32 * decltype(o)::value, b); },
+                    [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                        constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                        nlr_mma_f32<G == 0>(u.a[J], bj, f0, y[G >> 1].a[G & 1]);
+                    },
+                    [&](auto o, auto, const Unit<2> &u) {
+                        x[decltype(o)::value] = u;
+                        nlr_act_unit<true>(x[decltype(o)::value]);
+                    });
+#pragma unroll
+                for (int t = 0; t < WT; ++t) y[t] = x[t];
+            }
+            Unit<2> out1;
+            nlr_gemm<1, 2 * WT, 1, 2, 1, F_HID, 1>(
+                tp, [&](auto, f32x4(&b)[2]) { bias_rows(lds_bias + OB_VL + (P.depth - 2) * (WT * 32), b); },
+                [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
+                    constexpr int G = decltype(g)::value, J = decltype(j)::value;
+                    nlr_mma_f32<G == 0>(u.a[J], bj, f0, y[G >> 1].a[G & 1]);
+                },
+                [&](auto, auto, const Unit<2> &u) { out1 = u; });
+            if (q == 0) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const uint32_t smp = base + (2 * h + n) * 16 + col;
+                    if (smp < P.M) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float z = P.rgb_premul * out1.a[0][n][c] + P.rgb_bias;
+                            const float sg = 1.0f / (1.0f + expf(-z));
+                            P.rgb[(size_t)c * P.M + smp] = sg * (1.0f + 2.0f * P.rgb_padding) - P.rgb_padding;
+                        }
+                    }
+                }
+            }
+            nlr_pad<F_END % NLR_CHUNK_FRAGS>(tp);
+        };
+        pass(ic<0>{});
+        pass(ic<1>{});
     }
     }  // tile loop
     // the read-ahead DMA must not outlive the workgroup's LDS allocation
@@ -713,3 +906,4 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
 #define NLR_MLP_LAUNCH_NAME2(wt, ht, pr) nlr_mlp_launch_##wt##_##ht##_##pr
 #define NLR_MLP_LAUNCH_NAME(wt, ht, pr) NLR_MLP_LAUNCH_NAME2(wt, ht, pr)
 #define NLR_MLP_DECLARE(wt, ht, pr) void NLR_MLP_LAUNCH_NAME(wt, ht, pr)(const MlpParams &P, dim3 grid, hipStream_t st)
+
