@@ -405,6 +405,21 @@ __device__ __forceinline__ void nlr_gemm_pipe(Tape &tp, Unit<N> &last, const Bia
     nlr_run<OT, KG, RH, N, 1, F0, NP, NPP, PBY, DEFER, 0>(tp, prev, cur, bc, bn, last, bias, mma, epi, pend, [](auto) {});
 }
 
+// Diagnostic builds only (-DNLR_STAMPS, scripts/diag_build.sh): s_memtime at the phase boundaries of every workgroup's LAST tile,
+// written to a buffer of their own (nlr_stamp_buf) that nothing else reads; the product build contains no stamp.
+#ifdef NLR_STAMPS
+#define NLR_NSTAMP 24
+extern __device__ unsigned long long nlr_stamp_buf[1024 * NLR_NSTAMP];  // defined in nlr_mlp_inst.hip (same translation unit)
+#define NLR_STAMP(i)                                          \
+    do {                                                      \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        stamps[i] = __builtin_amdgcn_s_memtime();             \
+        __builtin_amdgcn_sched_barrier(0);                    \
+    } while (0)
+#else
+#define NLR_STAMP(i) do { } while (0)
+#endif
+
 // WT = view width / 32, BW = bottleneck / 32, FT = ceil(F / 32) grid-feature k-blocks, HT = head hidden units of 32 (0, 2 or 4)
 // PREC: NLR_PREC_F32 (all f32), NLR_PREC_MIXED (trunk+heads f32, view bf16), NLR_PREC_FAST (trunk+heads bf16x3, view bf16)
 #define NLR_BIAS_MAX 4096  // floats of LDS reserved for the bias block (16 KiB)
@@ -458,8 +473,17 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         out[1] = *reinterpret_cast<const f32x4 *>(b + 16 + 4 * q);
     };
 
+#ifdef NLR_STAMPS
+    unsigned long long stamps[NLR_NSTAMP];
+#pragma unroll
+    for (int i = 0; i < NLR_NSTAMP; ++i) stamps[i] = 0;
+#endif
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t base = tile * NLR_TILE + wave * 64;
+    NLR_STAMP(0);
+#ifdef NLR_STAMPS
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- inputs of the wave's 64 samples: grid features as f32 units (row block J = 2t + jb holds features 16J + 4q + r),
     // direction encoding of the sample's ray as one more 32-feature unit
     Unit<2> fin[2][FT], encu[2];
@@ -486,6 +510,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 encu[h].a[jb][n] = P.rgb ? *reinterpret_cast<const f32x4 *>(P.enc + (size_t)ray * 32 + 16 * jb + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
 
+    NLR_STAMP(1);  // input loads issued
     // per-sample outputs of one half: density, class probabilities, intensity (class-major / channel-major stores: the 16
     // lanes of a row write 64 consecutive bytes)
     auto heads_out = [&](auto hh, const float (&raw)[2], const Unit<2> &lo) {
@@ -553,6 +578,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 BT<2> fh[FT], fl[FT];
 #pragma unroll
                 for (int t = 0; t < FT; ++t) nlr_split_all<false, 0>(fh[t], fl[t], fin[h][t]);
+                if constexpr (h == 0) NLR_STAMP(2);  // features split
                 BT<2> dh[2], dl[2];
                 nlr_gemm<2, FT, 2, 2, 2, F0, 8>(
                     tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D0 + 32 * decltype(o)::value, b); },
@@ -561,6 +587,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                         nlr_mma_x3<G == 0, 0>(u.a[J], bj, f0, f1, fh[G], fl[G]);
                     },
                     [&](auto o, auto p, const Unit<2> &u) { nlr_split_piece<true, decltype(p)::value, 0>(dh[decltype(o)::value], dl[decltype(o)::value], u); });
+                if constexpr (h == 0) NLR_STAMP(3);  // D0
                 BT<2> hbl[BW];
                 nlr_gemm<BW, 2, 2, 2, 2, F0 + FR_D0, 8>(
                     tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D2 + 32 * decltype(o)::value, b); },
@@ -585,6 +612,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                             hbl[O].n[n][4 * jb + 2 * pr + e] = lv[e];
                         }
                     });
+                if constexpr (h == 0) NLR_STAMP(4);  // D2
                 if constexpr (HT > 0) {
                     BT<2> qh[HTA], ql[HTA];
                     nlr_gemm<HT, BW, 2, 2, 2, F0 + FR_D0 + FR_D2, 8>(
@@ -599,6 +627,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                             }
                         },
                         [&](auto o, auto p, const Unit<2> &u) { nlr_split_piece<true, decltype(p)::value, 0>(qh[decltype(o)::value], ql[decltype(o)::value], u); });
+                    if constexpr (h == 0) NLR_STAMP(5);  // H1
                     nlr_gemm<1, HT, 2, 2, 2, F0 + FR_D0 + FR_D2 + FR_H1, 1>(
                         tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_H2, b); },
                         [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &f1, const f32x4 &bj) {
@@ -657,10 +686,13 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                         [&](auto, auto, const Unit<2> &u) { lo = u; });
                 }
             }
+            if constexpr (h == 0) NLR_STAMP(6);  // H2
             heads_out(hh, raw, lo);
+            if constexpr (h == 0) NLR_STAMP(7);  // softmax + stores of half A
         };
         trunk(ic<0>{});
         trunk(ic<1>{});
+        NLR_STAMP(8);  // trunk + heads of half B
         if (P.rgb == nullptr) {  // density / semantic / intensity only (uniform for the whole grid)
             nlr_pad<F_VIEW % NLR_CHUNK_FRAGS>(tp);
             continue;
@@ -695,7 +727,9 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 2 * h>(x[WT - 1], cx); });
         };
         view01(ic<0>{});
+        NLR_STAMP(9);  // V0 + V1 of half A
         view01(ic<1>{});
+        NLR_STAMP(10);  // V0 + V1 of half B
         // hidden layers 2..depth-1 at full width (4 MFMAs per tape fragment), two per iteration (y -> x -> y) so that no
         // tile copies are needed.  The pending last unit of layer 1 is the concatenation of the two halves' units.
         Unit<4> cx4, cy4;
@@ -726,6 +760,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 [&](auto o, auto p, const Unit<4> &u) { nlr_pack_piece<true, decltype(p)::value, 0>(y[decltype(o)::value], u); },
                 [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 0>(x[WT - 1], cx4); });
         }
+        NLR_STAMP(11);  // hidden layer pairs
         const bool odd = ((P.depth - 2) & 1) != 0;
         if (odd) {  // odd number of hidden layers: one more, serial epilogue, result moved back into y
             const float *bl = lds_bias + OB_VL + (l - 2) * (WT * 32);
@@ -754,6 +789,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 tp, cx4, [&](auto, f32x4(&b)[2]) { bias_rows(brgb, b); }, rgb_mma, [&](auto, auto, const Unit<4> &u) { out1 = u; },
                 [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 0>(y[WT - 1], cy4); });
         }
+        NLR_STAMP(12);  // rgb layer
         if (q == 0) {  // rows 0..2 of the output unit sit on lanes 0..15
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -768,7 +804,17 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 }
             }
         }
+        NLR_STAMP(13);  // rgb stores
         nlr_pad<F_END % NLR_CHUNK_FRAGS>(tp);
+        NLR_STAMP(14);  // tape padding
+#ifdef NLR_STAMPS
+        if (tile + gridDim.x >= ntiles && threadIdx.x == 0 && blockIdx.x < 1024) {
+            unsigned long long *dbg = nlr_stamp_buf + (size_t)blockIdx.x * NLR_NSTAMP;
+            for (int i = 0; i < 15; ++i) dbg[i] = stamps[i];
+            dbg[22] = rt0;
+            dbg[23] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
     } else {
         // =================================================== exact-f32 chain: each half runs the whole tape ======================
         auto pass = [&](auto hh) {

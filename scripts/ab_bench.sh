@@ -4,7 +4,7 @@
 R=${ROUNDS:-3}
 for i in $(seq $R); do
   for L in "$@"; do
-    NLR_LIB_PATH=$L timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | \
+    NLR_LIB_PATH=$L timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 | \
       python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms']; print('$L', round(d['ms_per_step'],3), {a: round(b,4) for a,b in k.items()})"
   done
 done

@@ -1,5 +1,6 @@
-"""Diagnostic: per-phase cycle shares of nlr_mlp_kernel from s_memtime stamps (stamp build only; never shipped)."""
-import os, sys
+"""Diagnostic: per-phase cycle shares of nlr_mlp_kernel from s_memtime stamps (a -DNLR_STAMPS build only; never shipped).
+    TAG=stamps EXTRA=-DNLR_STAMPS scripts/diag_build.sh;  NLR_LIB_PATH=nerf-lidar_amd/build/var/lib_stamps.so python scripts/stamp_probe.py"""
+import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nerf-lidar_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -9,26 +10,19 @@ mc = nconfig.workload("C2"); sd = nweights.synth_state_dict(mc, seed=0, trained_
 m = Model(mc, sd, precision=2)
 b = nlidar.synthetic_sweep(width=1024, seed=0)
 batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
-N = 32768
-need = _lib.lib().nlr_workspace_bytes(m._handle, N)
-m._ws = torch.zeros(need + (4 << 20), dtype=torch.uint8, device="cuda")
-al = lambda x: (x + 255) & ~255
-off = 0
-for S in (64, 64):
-    off += 2 * al(N * (S + 1) * 4) + 2 * al(N * S * 4)
-S = 128
-off += 2 * al(N * (S + 1) * 4) + 2 * al(N * S * 4)   # sdist, tdist, weights, density
-off += al(N * S * 40 * 4) + al(N * 32 * 4) + al(N * S * 3 * 4) + al(N * S * 19 * 4)   # feat, enc, rgb, sem
-inten_off = off
-for _ in range(3): m.render_rays(batch)
+for _ in range(200): m.render_rays(batch)   # ~2 s of back-to-back sweeps so that the clock settles
 torch.cuda.synchronize()
-raw = m._ws[inten_off + N * S * 4: inten_off + N * S * 4 + 256 * 128].cpu().numpy().view(np.uint64).reshape(256, 16)  # one row per persistent workgroup (its last tile)
-d = np.diff(raw[:, :7].astype(np.int64), axis=1)
-clk = (raw[:, 7].astype(np.int64) - raw[:, 0].astype(np.int64)) / np.maximum(raw[:, 9].astype(np.int64) - raw[:, 8].astype(np.int64), 1) * 100.0
-print("in-kernel clock (MHz, median over blocks):", np.median(clk))
-ok = (d > 0).all(1) & (d < 10**7).all(1)
-print("blocks with sane stamps:", ok.sum())
-names = ["prologue+trunk+heads", "softmax/stores", "V0 (144 mfma)", "V1 (272 mfma)", "hidden x6 (768 mfma)", "rgb (16 mfma)"]
+NS = 24
+raw = np.zeros(1024 * NS, np.uint64)
+L = _lib.lib()
+assert L.nlr_debug_stamps(raw.ctypes.data_as(C.c_void_p), C.c_size_t(raw.size)) == 0
+raw = raw.reshape(1024, NS)[:256].astype(np.int64)
+names = ["input loads issued", "feature split (half A)", "D0 (A)", "D2 (A)", "H1 (A)", "H2 (A)", "softmax + stores (A)", "trunk + heads (B)",
+         "V0 + V1 (A)", "V0 + V1 (B)", "hidden layer pairs", "rgb layer", "rgb stores", "tape padding"]
+d = np.diff(raw[:, :15], axis=1)
+ok = (d >= 0).all(1) & (d < 10**7).all(1) & (raw[:, 0] > 0)
+clk = (raw[:, 14] - raw[:, 0]) / np.maximum(raw[:, 23] - raw[:, 22], 1) * 100.0
+print("blocks with sane stamps:", int(ok.sum()), " in-kernel clock (MHz, median):", float(np.median(clk[ok])))
 med = np.median(d[ok], axis=0)
-for n, v in zip(names, med): print(f"  {n:24s} {v:10.0f} ticks ({100*v/med.sum():5.1f} %)")
-print("  total", med.sum())
+for n, v in zip(names, med): print(f"  {n:28s} {v:10.0f} cycles ({100 * v / med.sum():5.1f} %)")
+print(f"  total per 256-sample tile     {med.sum():10.0f} cycles")
