@@ -238,7 +238,7 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     lv.prec = prec;
     const int crit = (prec == NLR_PREC_FAST) ? TAPE_X3 : TAPE_F32;   // density trunk + heads
     const int view = (prec == NLR_PREC_F32) ? TAPE_F32 : TAPE_BF16;  // view MLP
-    // The tile's program (nlr_mlp_kernel.h): bf16 view MLP: [T T V0 V1 V0 V1 | hidden.. | RGB] (the trunk + heads T and view
+    // The tile's program (nlr_mlp_kernel.h): bf16 view MLP: [T V0 V1 | T V0 V1 | hidden.. | RGB] (the trunk + heads T and view
     // layers 0/1 run once per 32-sample half); exact-f32 chain: [T V0 V1 | hidden.. | RGB], consumed once per half.
     std::vector<float> bias;  // b_d0 | b_d2 | b_h1 | b_h2 | view0 | view1 | view2.. | rgb, each padded to whole units of 32
     auto push_bias = [&](const float *b, uint32_t n, uint32_t pad) {
@@ -306,8 +306,8 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
         append(v01);
     } else {
         append(trunk);
-        append(trunk);
         append(v01);
+        append(trunk);
         append(v01);
     }
     for (uint32_t l = 2; l < lv.D; ++l) {
@@ -322,7 +322,7 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     push_bias(d.rgb_layer.bias, 3, 32);
     tb.pad_to_chunk();
     lv.bias_count = (uint32_t)bias.size();
-    NLR_CHECK_ARG(lv.bias_count <= 4096, "bias block of %u floats exceeds the 4096-float LDS reservation", lv.bias_count);
+    NLR_CHECK_ARG(lv.bias_count <= 3072, "bias block of %u floats exceeds the 3072-float LDS reservation (view MLP too deep / wide)", lv.bias_count);
     if ((rc = dev_upload(m, bias.data(), bias.size() * 4, (void **)&lv.bias_all))) return rc;
     lv.tape_chunks = (uint32_t)(tb.bytes.size() / NLR_TAPE_CHUNK);
     tb.bytes.resize(tb.bytes.size() + 3 * NLR_TAPE_CHUNK, 0);  // slack: the kernel prefetches up to 3 chunks past the end
@@ -452,11 +452,13 @@ static size_t level_ws(const LevelModel &lv, uint32_t N, bool last) {
     b += 2 * al((size_t)N * (S + 1) * 4);  // sdist, tdist
     b += 2 * al((size_t)N * S * 4);        // weights, density
     if (!lv.is_prop) {
-        b += al((size_t)N * S * lv.F * 4);               // features
+        b += al((size_t)N * S * lv.F * 4 + 1024);        // features (+ slack: the MLP kernel stages 64-sample windows)
         b += al((size_t)N * S * 3 * 4);                  // rgb
         b += al((size_t)N * S * (lv.K ? lv.K : 1) * 4);  // semantic
         b += al((size_t)N * S * 4);                      // intensity
         b += al((size_t)N * 32 * 4);                     // per-ray direction encoding
+        b += al((size_t)N * 4);                          // |directions| (compositing mode)
+        b += al((size_t)N * S * 4);                      // segment records (compositing mode: N * S / 32 records of 32 floats)
     }
     (void)last;
     return b;
@@ -470,9 +472,11 @@ extern "C" size_t nlr_workspace_bytes(const NlrModel *m, uint32_t N) {
 }
 
 // Run encode + MLP of one NerfMLP level (or the fused proposal kernel) for given tdist.
+// seg != NULL: compositing mode (rgb / sem / inten are not written; see nlr_mlp_kernel.h) - needs dnorm [N] scratch
 static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays *rays, const float *tdist, uint32_t N,
                          uint32_t n, uint32_t mloops, const float *rand_deg, float *feat, float *raybias, float *density,
-                         float *rgb, float *sem, float *inten, float *prop_feat, hipStream_t st, bool internal_feat = false) {
+                         float *rgb, float *sem, float *inten, float *prop_feat, hipStream_t st, bool internal_feat = false,
+                         float *seg = nullptr, float *dnorm = nullptr) {
     // features in the workspace (never seen by the caller) take the piece-major layout when the fast kernels apply
     const int piece_major = (internal_feat && !lv.is_prop && lv.gp.C == 4 && n <= 8 && lv.F % 4 == 0) ? 1 : 0;
     CastParams cp;
@@ -486,10 +490,12 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
         ProfScope ps(&m->prof, NLR_K_ENCODE, st);
         if ((rc = nlr_launch_encode(cp, lv.gp, lv.re_weights, feat, piece_major, st))) return rc;
     }
-    if (rgb) {
+    if (rgb || seg) {
         NLR_CHECK_ARG(rays->viewdirs != nullptr, "NerfMLP: viewdirs is NULL");
         DirEncParams dp;
         dp.viewdirs = rays->viewdirs;
+        dp.dirs = seg ? rays->directions : nullptr;
+        dp.dnorm = seg ? dnorm : nullptr;
         dp.N = N;
         dp.deg = lv.deg;
         dp.E = lv.E;
@@ -510,16 +516,20 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
     P.bias_count = lv.bias_count;
     P.enc = raybias;
     P.depth = lv.D;
-    P.K = sem ? lv.K : 0;
+    P.K = (sem || seg) ? lv.K : 0;
     P.int_row = lv.int_row;
+    P.tdist = tdist;
+    P.dnorm = dnorm;
+    P.seg = seg;
+    P.opaque = m->opaque;
     P.density_bias = lv.density_bias;
     P.rgb_premul = lv.rgb_premul;
     P.rgb_bias = lv.rgb_bias;
     P.rgb_padding = lv.rgb_padding;
     P.density = density;
-    P.rgb = rgb;
+    P.rgb = seg ? seg : rgb;  // (compositing mode: non-NULL = run the view MLP; nothing is stored through it)
     P.sem = sem;
-    P.inten = (lv.use_int && inten) ? inten : nullptr;
+    P.inten = (lv.use_int && (inten || seg)) ? (seg ? seg : inten) : nullptr;  // (compositing mode: non-NULL = the records carry the intensity)
     ProfScope ps(&m->prof, NLR_K_MLP, st);
     return nlr_launch_mlp(P, lv.W, lv.WB, lv.HT, lv.prec, m->cus, st);
 }
@@ -536,7 +546,7 @@ extern "C" int nlr_mlp_level(const NlrModel *m, uint32_t level, const NlrRays *r
         return run_mlp_level(m, lv, rays, tdist, N, sample_n, sample_m, rand_deg, nullptr, nullptr, density, nullptr, nullptr,
                              nullptr, features, st);
     Carve c(workspace, workspace_bytes);
-    float *feat = features ? features : c.take((size_t)N * lv.S * lv.F);
+    float *feat = features ? features : c.take((size_t)N * lv.S * lv.F + 256);
     float *rb = c.take((size_t)N * 32);
     float *sem = semantic ? semantic : (lv.K ? c.take((size_t)N * lv.S * lv.K) : nullptr);
     if (c.off > workspace_bytes || (!workspace && c.off))
@@ -584,21 +594,35 @@ extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t 
                                      jit, lv.max_jitter, rays->near, rays->far, m->power_lambda, N, sdist, tdist, st);
         }
         if (rc) return rc;
-        float *feat = nullptr, *rb = nullptr, *rgb = nullptr, *sem = nullptr, *inten = nullptr;
+        float *feat = nullptr, *rb = nullptr, *rgb = nullptr, *sem = nullptr, *inten = nullptr, *seg = nullptr, *dnorm = nullptr;
+        // Compositing mode: nobody asked for the per-sample heads of the last level (ray_history), so the MLP kernel composites
+        // inside its 32-sample segments and 24 floats per sample never go to HBM.
+        const bool fuse = last && !lv.is_prop && !ho.rgb && !ho.semantic && !ho.intensity && lv.gp.C == 4 && n <= 8 &&
+                          nlr_mlp_can_composite(lv.W, lv.WB, lv.HT, lv.prec, lv.F, S, lv.K, lv.use_int, (uint64_t)N * S);
         if (!lv.is_prop) {
-            feat = c.take((size_t)N * S * lv.F);
+            feat = c.take((size_t)N * S * lv.F + 256);
             rb = c.take((size_t)N * 32);
-            rgb = ho.rgb ? ho.rgb : c.take((size_t)N * S * 3);
-            sem = lv.K ? (ho.semantic ? ho.semantic : c.take((size_t)N * S * lv.K)) : nullptr;
-            inten = lv.use_int ? (ho.intensity ? ho.intensity : c.take((size_t)N * S)) : nullptr;
+            if (fuse) {
+                dnorm = c.take((size_t)N);
+                seg = c.take((size_t)N * S);
+            } else {
+                rgb = ho.rgb ? ho.rgb : c.take((size_t)N * S * 3);
+                sem = lv.K ? (ho.semantic ? ho.semantic : c.take((size_t)N * S * lv.K)) : nullptr;
+                inten = lv.use_int ? (ho.intensity ? ho.intensity : c.take((size_t)N * S)) : nullptr;
+            }
         }
-        rc = run_mlp_level(m, lv, rays, tdist, N, n, mloops, cfg->rand_deg[l], feat, rb, density, rgb, sem, inten, nullptr, st, true);
+        rc = run_mlp_level(m, lv, rays, tdist, N, n, mloops, cfg->rand_deg[l], feat, rb, density, rgb, sem, inten, nullptr, st, true, seg,
+                           dnorm);
         if (rc) return rc;
         {
             ProfScope ps(&m->prof, NLR_K_COMPOSITE, st);
-            rc = nlr_composite_level(density, tdist, rays->directions, last ? rgb : nullptr, last ? sem : nullptr, last ? inten : nullptr,
-                                     rays->far, rays->origins, N, S, lv.K, (int)m->opaque, m->bg, last ? (int)cfg->compute_extras : 0,
-                                     last ? cfg->scale_factor : 0.0f, weights, last ? out : nullptr, ho.depth, st);
+            if (fuse)
+                rc = nlr_composite_segments(density, tdist, rays->directions, seg, lv.K, lv.use_int ? 1 : 0, rays->far, rays->origins, N, S,
+                                            (int)m->opaque, m->bg, (int)cfg->compute_extras, cfg->scale_factor, weights, out, ho.depth, st);
+            else
+                rc = nlr_composite_level(density, tdist, rays->directions, last ? rgb : nullptr, last ? sem : nullptr, last ? inten : nullptr,
+                                         rays->far, rays->origins, N, S, lv.K, (int)m->opaque, m->bg, last ? (int)cfg->compute_extras : 0,
+                                         last ? cfg->scale_factor : 0.0f, weights, last ? out : nullptr, ho.depth, st);
         }
         if (rc) return rc;
         prev_s = sdist;

@@ -98,12 +98,37 @@ __global__ void __launch_bounds__(256) nlr_composite_kernel(CompositeParams P) {
     const float accc = fmaxf(acc, NLR_EPS);
     const float depth = sdep / accc;
     const float bgw = fmaxf(1.0f - acc, 0.0f);
-    if (P.rgb || P.o_rgb) {
+    int label = 0;
+    float segv = 0.0f;  // segment mode: lane c < 32 holds slot c of the ray's record
+    if (P.seg) {
+        // The MLP kernel (compositing mode) has already summed w' x value inside every 32-sample segment, with w' = the alpha
+        // weight relative to the segment start; the ray's value is sum_s T_s * record_s with T_s = exp(-sum of sigma*delta in
+        // front of segment s) = exp(-base) of the lane that owns the segment's first sample (32 % per == 0: checked by the host).
+        const float tseg = expf(-base);
+        const uint32_t nseg = S >> 5;
+        const float *rec = P.seg + (size_t)(active ? ray : 0) * nseg * 32 + (lane & 31);
+        for (uint32_t s = 0; s < nseg; ++s) segv += __shfl(tseg, (int)((32 * s) / per), 64) * rec[(size_t)s * 32];
+        // label = first maximum over slots [0, K)
+        float bv = ((uint32_t)(lane & 31) < P.K) ? segv : -INFINITY;
+        int bi = lane & 31;
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(bv, d, 64);
+            const int oi = __shfl_xor(bi, d, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        label = bi;
+        sint = __shfl(segv, (int)P.K, 64);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) srgb[c] = __shfl(segv, 29 + c, 64);
+    } else if (P.rgb || P.o_rgb) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) srgb[c] = nlr_wave_sum(srgb[c]);
     }
     if (P.inten) sint = nlr_wave_sum(sint);
-    int label = 0;
     if (P.sem) {
         float best = -INFINITY;
 #pragma unroll
@@ -124,13 +149,13 @@ __global__ void __launch_bounds__(256) nlr_composite_kernel(CompositeParams P) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) P.o_rgb[(size_t)ray * 3 + c] = srgb[c] + bgw * P.bg;
         }
-        if (P.o_int && P.inten) P.o_int[ray] = sint;
+        if (P.o_int && (P.inten || (P.seg && P.seg_int))) P.o_int[ray] = sint;
         if (P.o_sem && P.sem) {
 #pragma unroll
             for (int c = 0; c < NLR_COMP_MAXK; ++c)
                 if (c < (int)P.K) P.o_sem[(size_t)ray * P.K + c] = ssem[c];
         }
-        if (P.o_labels && P.sem) P.o_labels[ray] = label;
+        if (P.o_labels && (P.sem || (P.seg && P.K))) P.o_labels[ray] = label;
         if (P.o_points && P.origins) {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -141,13 +166,14 @@ __global__ void __launch_bounds__(256) nlr_composite_kernel(CompositeParams P) {
             const uint32_t row = P.pk_h ? (ray % P.pk_w) * P.pk_h + ray / P.pk_w : ray;
             float *pk = P.o_packed + (size_t)row * 7;
             pk[0] = depth;
-            pk[1] = P.inten ? sint : 0.0f;
+            pk[1] = (P.inten || (P.seg && P.seg_int)) ? sint : 0.0f;
             pk[2] = acc;
 #pragma unroll
             for (int c = 0; c < 3; ++c) pk[3 + c] = srgb[c] + bgw * P.bg;
             pk[6] = (float)label;
         }
     }
+    if (P.seg && active && P.o_sem && (uint32_t)lane < P.K) P.o_sem[(size_t)ray * P.K + lane] = segv;
     if (!P.extras) return;  // uniform across the block
 
     // distance_mean (render.py:266-269)
@@ -205,6 +231,7 @@ int nlr_launch_composite(const CompositeParams &P, hipStream_t st) {
     NLR_CHECK_ARG(P.S >= 1 && P.S <= 64 * NLR_COMP_MAXPER, "composite: S=%u outside [1,%d]", P.S, 64 * NLR_COMP_MAXPER);
     NLR_CHECK_ARG(P.K <= NLR_COMP_MAXK, "composite: class_num %u > %d", P.K, NLR_COMP_MAXK);
     NLR_CHECK_ARG(P.density && P.tdist && P.dirs, "composite: NULL density/tdist/directions");
+    NLR_CHECK_ARG(!P.seg || (P.S % 32 == 0 && 32 % ((P.S + 63) / 64) == 0 && P.K + P.seg_int <= 29), "composite: segment records do not fit S = %u, K = %u", P.S, P.K);
     NLR_CHECK_ARG(!P.extras || P.far, "composite: compute_extras needs the far plane");
     const size_t lds = (size_t)4 * 2 * (P.S + 2) * sizeof(float);
     hipLaunchKernelGGL(nlr_composite_kernel, dim3((P.N + 3) / 4), dim3(256), lds, st, P);
@@ -257,4 +284,50 @@ extern "C" int nlr_composite_level(const float *density, const float *tdist, con
                           "composite: packed tile %u x %u does not match N = %u rays", out->packed_h, out->packed_w, N);
     }
     return nlr_launch_composite(P, (hipStream_t)stream);
+}
+
+// Compositing-mode tail of nlr_render_rays: weights / depth / acc / percentiles from density and tdist as above, the per-ray rgb /
+// semantic / intensity from the segment records nlr_mlp_kernel<..., COMP = true> wrote (nlr_mlp_kernel.h).
+int nlr_composite_segments(const float *density, const float *tdist, const float *directions, const float *seg, uint32_t class_num,
+                           int has_intensity, const float *far, const float *origins, uint32_t N, uint32_t S, int opaque_background,
+                           float bg, int compute_extras, float scale_factor, float *weights, const NlrOut *out, float *level_depth,
+                           hipStream_t st) {
+    if (N == 0) return NLR_OK;
+    NLR_CHECK_ARG(seg && out, "composite_segments: NULL argument");
+    CompositeParams P;
+    memset(&P, 0, sizeof(P));
+    P.density = density;
+    P.tdist = tdist;
+    P.dirs = directions;
+    P.seg = seg;
+    P.seg_int = has_intensity ? 1 : 0;
+    P.far = far;
+    P.origins = origins;
+    P.N = N;
+    P.S = S;
+    P.K = class_num;
+    P.opaque = opaque_background;
+    P.extras = compute_extras;
+    P.bg = bg;
+    P.scale_factor = scale_factor > 0 ? scale_factor : 1.0f;
+    P.weights = weights;
+    P.level_depth = level_depth;
+    P.o_rgb = out->rgb;
+    P.o_depth = out->depth;
+    P.o_sem = out->semantic;
+    P.o_int = out->intensity;
+    P.o_acc = out->acc;
+    P.o_dmean = out->distance_mean;
+    P.o_dmed = out->distance_median;
+    P.o_p5 = out->distance_percentile_5;
+    P.o_p95 = out->distance_percentile_95;
+    P.o_labels = out->labels;
+    P.o_points = scale_factor > 0 ? out->points : nullptr;
+    P.o_packed = out->packed;
+    P.pk_h = out->packed_h;
+    P.pk_w = out->packed_w;
+    if (out->packed && out->packed_h)
+        NLR_CHECK_ARG(out->packed_w > 0 && (uint64_t)out->packed_h * out->packed_w == N,
+                      "composite: packed tile %u x %u does not match N = %u rays", out->packed_h, out->packed_w, N);
+    return nlr_launch_composite(P, st);
 }

@@ -22,6 +22,8 @@ struct CompositeParams {
     float *weights;  // [N,S] or null
     float *o_rgb, *o_depth, *o_sem, *o_int, *o_acc, *o_dmean, *o_dmed, *o_p5, *o_p95, *o_points, *level_depth;
     int32_t *o_labels;
+    const float *seg;        // (instead of rgb / sem / inten) segment records of the compositing-mode MLP kernel, int_row = K
+    uint32_t seg_int;        // the records carry the intensity in slot K
     float *o_packed;         // [N, 7] records (see NlrOut.packed)
     uint32_t pk_h, pk_w;
 };
@@ -51,12 +53,19 @@ struct MlpParams {
     uint32_t K, int_row;    // class_num (0 = no semantic head), row of the intensity output (or 0xffffffff)
     float density_bias, rgb_premul, rgb_bias, rgb_padding;
     float *density, *rgb, *sem, *inten;  // outputs: [M], channel-major [3,M], class-major [K,M], [M]
+    // compositing mode (see nlr_mlp_kernel.h, COMP): instead of rgb / sem / inten one 32-float record per 32-sample segment
+    const float *tdist;     // [N, S+1]
+    const float *dnorm;     // [N] |directions|
+    float *seg;             // [M / 32, 32]
+    uint32_t opaque;
 };
 
 struct DirEncParams {
     const float *viewdirs;  // [N,3]
+    const float *dirs;      // [N,3] or null
     uint32_t N, deg, E;
     float *out;             // [N, 32]
+    float *dnorm;           // [N] |dirs| or null
 };
 
 int nlr_launch_resample(const float *prev_sdist, const float *prev_weights, uint32_t n_prev, float dilation, float anneal,
@@ -70,4 +79,10 @@ int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1,
                     float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st);
 int nlr_launch_direnc(const DirEncParams &P, hipStream_t st);
 int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, uint32_t cus, hipStream_t st);
+// can nlr_launch_mlp run this level in compositing mode (MlpParams.seg)?
+bool nlr_mlp_can_composite(uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, uint32_t F, uint32_t S, uint32_t K, bool use_int, uint64_t M);
 int nlr_launch_composite(const CompositeParams &P, hipStream_t st);
+int nlr_composite_segments(const float *density, const float *tdist, const float *directions, const float *seg, uint32_t class_num,
+                           int has_intensity, const float *far, const float *origins, uint32_t N, uint32_t S, int opaque_background,
+                           float bg, int compute_extras, float scale_factor, float *weights, const NlrOut *out, float *level_depth,
+                           hipStream_t st);

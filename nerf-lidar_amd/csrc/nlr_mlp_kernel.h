@@ -192,6 +192,22 @@ __device__ __forceinline__ void nlr_pad(Tape &tp) {
     }
 }
 
+// K steps from position F whose fragments are ignored (a part of the tile's program that this launch does not run): whole
+// chunks in a runtime loop, the remainder unrolled
+template <int F, int K>
+__device__ __forceinline__ void nlr_skip_few(Tape &tp) {
+    if constexpr (K > 0) {
+        (void)tp.template step<F % NLR_CHUNK_FRAGS>();
+        __builtin_amdgcn_sched_barrier(0);
+        nlr_skip_few<F % NLR_CHUNK_FRAGS + 1, K - 1>(tp);
+    }
+}
+template <int F, int K>
+__device__ __forceinline__ void nlr_skip(Tape &tp) {
+    for (int c = 0; c < K / NLR_CHUNK_FRAGS; ++c) nlr_skip_few<F, NLR_CHUNK_FRAGS>(tp);
+    nlr_skip_few<F, K % NLR_CHUNK_FRAGS>(tp);
+}
+
 // ---- register tiles ---------------------------------------------------------------------------------------------------
 // N = 16-sample column tiles held by the wave (4 = 64 samples, 2 = 32 samples: half width).
 // Unit: 32 output rows x 16N samples of f32 accumulators: a[jb][n][r] on lane (col, rb) is row 16*jb + 4*rb + r of column
@@ -319,6 +335,27 @@ __device__ __forceinline__ float nlr_q_max(float v) {
     return fmaxf(__builtin_bit_cast(float, (uint32_t)b[0]), __builtin_bit_cast(float, (uint32_t)b[1]));
 }
 
+// DPP moves inside a 16-lane row (= the 16 samples of one column tile); lanes without a source lane read 0
+template <int CTRL>
+__device__ __forceinline__ float nlr_dpp0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float nlr_row_incl_scan(float v) {  // Hillis-Steele over the 16 lanes of a row (row_shr:1,2,4,8)
+    v += nlr_dpp0<0x111>(v);
+    v += nlr_dpp0<0x112>(v);
+    v += nlr_dpp0<0x114>(v);
+    v += nlr_dpp0<0x118>(v);
+    return v;
+}
+__device__ __forceinline__ float nlr_row_shr1(float v) { return nlr_dpp0<0x111>(v); }  // lane c <- lane c-1, lane 0 <- 0
+__device__ __forceinline__ float nlr_row_sum(float v) {  // butterfly: every lane of the row gets the row's sum
+    v += nlr_dpp0<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += nlr_dpp0<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += nlr_dpp0<0x141>(v);  // row_half_mirror
+    v += nlr_dpp0<0x140>(v);  // row_mirror
+    return v;
+}
+
 // ---- GEMM driver ---------------------------------------------------------------------------------------------------------
 // One GEMM = OT output units (32 rows; RH = 2 row blocks of 16, or RH = 1: only the first 16 rows exist) x KG k-groups
 // (32 input features per group on the bf16 paths, 16 on the exact-f32 path), N column tiles.  Tape order: unit-major, then
@@ -398,11 +435,17 @@ __device__ __forceinline__ void nlr_gemm(Tape &tp, const Bias &bias, const Mma &
     nlr_run<OT, KG, RH, N, FPS, F0, NP, 0, 1, false, 0>(tp, prev, cur, bc, bn, last, bias, mma, epi, [](auto) {}, [](auto) {});
 }
 // software-pipelined across GEMMs: pend = the previous GEMM's deferred unit, last = this GEMM's (when DEFER)
-template <int OT, int KG, int RH, int N, int F0, int NP, int NPP, int PBY, bool DEFER, class Bias, class Mma, class Epi, class Pend>
-__device__ __forceinline__ void nlr_gemm_pipe(Tape &tp, Unit<N> &last, const Bias &bias, const Mma &mma, const Epi &epi, const Pend &pend) {
+// bg(ic<step>): background work of the caller (compositing pieces), one call per step
+template <int OT, int KG, int RH, int N, int F0, int NP, int NPP, int PBY, bool DEFER, class Bias, class Mma, class Epi, class Pend, class Bg>
+__device__ __forceinline__ void nlr_gemm_pipe(Tape &tp, Unit<N> &last, const Bias &bias, const Mma &mma, const Epi &epi, const Pend &pend,
+                                              const Bg &bg) {
     Unit<N> prev, cur;
     f32x4 bc[2], bn[2];
-    nlr_run<OT, KG, RH, N, 1, F0, NP, NPP, PBY, DEFER, 0>(tp, prev, cur, bc, bn, last, bias, mma, epi, pend, [](auto) {});
+    nlr_run<OT, KG, RH, N, 1, F0, NP, NPP, PBY, DEFER, 0>(tp, prev, cur, bc, bn, last, bias, mma, epi, pend, bg);
+}
+template <int OT, int KG, int RH, int N, int F0, int NP, int NPP, int PBY, bool DEFER, class Bias, class Mma, class Epi, class Pend>
+__device__ __forceinline__ void nlr_gemm_pipe(Tape &tp, Unit<N> &last, const Bias &bias, const Mma &mma, const Epi &epi, const Pend &pend) {
+    nlr_gemm_pipe<OT, KG, RH, N, F0, NP, NPP, PBY, DEFER>(tp, last, bias, mma, epi, pend, [](auto) {});
 }
 
 // Diagnostic builds only (-DNLR_STAMPS, scripts/diag_build.sh): s_memtime at the phase boundaries of every workgroup's LAST tile,
@@ -422,12 +465,25 @@ extern __device__ unsigned long long nlr_stamp_buf[1024 * NLR_NSTAMP];  // defin
 
 // WT = view width / 32, BW = bottleneck / 32, FT = ceil(F / 32) grid-feature k-blocks, HT = head hidden units of 32 (0, 2 or 4)
 // PREC: NLR_PREC_F32 (all f32), NLR_PREC_MIXED (trunk+heads f32, view bf16), NLR_PREC_FAST (trunk+heads bf16x3, view bf16)
-#define NLR_BIAS_MAX 4096  // floats of LDS reserved for the bias block (16 KiB)
+#define NLR_BIAS_MAX 3072  // floats of LDS reserved for the bias block (12 KiB)
 #define NLR_TILE 256       // samples per workgroup tile: 4 waves x 64
-template <int WT, int BW, int FT, int HT, int PREC>
+// Input staging (per wave): the NEXT tile's grid features (piece-major: one 1 KiB LDS-DMA per 4-feature piece and wave), the
+// direction-encoding rows of its rays (one gathering LDS-DMA) [and its sample distances] land in LDS while the current tile
+// computes; a tile starts by reading its inputs from LDS.  No registers and ~1 issue slot per KiB for the prefetch.
+#define NLR_STAGE_PIECES 11                           // up to 44 grid features are staged (more: direct global loads)
+#define NLR_STAGE_ENC (NLR_STAGE_PIECES * 256)        // float offset of the enc rows [n-tile][row block][q] x 4 floats
+#define NLR_STAGE_TD (NLR_STAGE_ENC + 128)            // float offset of t_k [64], t_k+1 [64], |d| [64], last-sample flag [64]
+#define NLR_STAGE_FLOATS (NLR_STAGE_TD + 256)
+// COMP: compositing mode (render path).  A 32-sample half of a wave is one segment of one ray (S % 32 == 0): the kernel turns the
+//   density into segment-local alpha weights w'_k = alpha_k exp(-sum_{j<k, j in segment} sigma_j delta_j) (16-lane DPP scan) and
+//   writes, instead of 24 floats per SAMPLE (class probabilities, intensity, rgb), one 32-float record per SEGMENT:
+//   [0,K) sum w' p_c, [K] sum w' intensity, [29,32) sum w' rgb.  nlr_composite_kernel scales each record by the transmittance at
+//   its segment start.  All of it is VALU work issued piece by piece behind the MFMAs of view layers 0 and 1.
+template <int WT, int BW, int FT, int HT, int PREC, bool COMP>
 __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     __shared__ __align__(16) uint4 lds_tape[NLR_NBUF * NLR_CHUNK_SLOTS];
     __shared__ __align__(16) float lds_bias[NLR_BIAS_MAX];
+    __shared__ __align__(16) float lds_stage[4 * NLR_STAGE_FLOATS];
     __shared__ uint32_t lds_sig;
     constexpr bool VIEW_F32 = (PREC == NLR_PREC_F32);
     constexpr bool X3 = (PREC == NLR_PREC_FAST);
@@ -447,9 +503,9 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     constexpr int FR_V0 = WT * ((BW + 1) * VK) * 2, FR_V1 = WT * ((WT + BW + 1) * VK) * 2;
     constexpr int FR_HL = WT * (WT * VK) * 2, FR_RGB = (WT * VK);
     static_assert(FR_HL % NLR_CHUNK_FRAGS == 0, "hidden view layers must cover whole chunks (width 128 or 256)");
-    // bf16 view MLP: [T T V0 V1 V0 V1 | hidden x (depth-2) | RGB];  f32 view MLP: [T V0 V1 | hidden | RGB] once per half
-    constexpr int F_VIEW = VIEW_F32 ? FR_T : 2 * FR_T;
-    constexpr int F_HID = VIEW_F32 ? FR_T + FR_V0 + FR_V1 : 2 * (FR_T + FR_V0 + FR_V1);
+    // bf16 view MLP: [T V0 V1 | T V0 V1 | hidden x (depth-2) | RGB];  f32 view MLP: [T V0 V1 | hidden | RGB] once per half
+    constexpr int FR_HALF = FR_T + FR_V0 + FR_V1;
+    constexpr int F_HID = VIEW_F32 ? FR_HALF : 2 * FR_HALF;
     constexpr int F_END = F_HID + FR_RGB;                 // (+ hidden layers: whole chunks)
 
     const uint32_t ntiles = (P.M + NLR_TILE - 1) / NLR_TILE;
@@ -461,8 +517,8 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
     tp.lds = lds_tape;
     tp.sig = &lds_sig;
     tp.sig_addr = (uint32_t)(uintptr_t)(nlr_lptr)&lds_sig;
-    // without the view MLP a tile consumes the trunk + head fragments only (padded to whole chunks)
-    tp.total = P.rgb ? (int)P.tape_chunks : nlr_ceil_div(F_VIEW, NLR_CHUNK_FRAGS);
+    // without the view MLP (density / semantic / intensity only: not a hot path) the view layers' fragments are stepped over
+    tp.total = P.rgb ? (int)P.tape_chunks : nlr_ceil_div(VIEW_F32 ? FR_T : F_HID, NLR_CHUNK_FRAGS);
     tp.tid = threadIdx.x;
     tp.lane = lane;
     tp.prologue();  // ends with __syncthreads(): the bias block is visible too
@@ -472,6 +528,74 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         out[0] = *reinterpret_cast<const f32x4 *>(b + 4 * q);
         out[1] = *reinterpret_cast<const f32x4 *>(b + 16 + 4 * q);
     };
+
+    // ---- input staging (see NLR_STAGE_*).  The wave's 64 samples start at stage_base(tile): `base`, pulled back inside the
+    // buffer for the last, partial tile (the samples past M are computed and dropped).
+    // (COMP: required, checked by the host.  The feature buffer is followed by >= 1 KiB of workspace: a window that starts inside
+    // it may run past its end when M < 64; those samples are computed and dropped.)
+    const bool staged = P.feat_piece_major && P.F <= 4 * NLR_STAGE_PIECES && P.rgb != nullptr;
+    float *stg = lds_stage + wave * NLR_STAGE_FLOATS;
+    const uint32_t stg_lds = (uint32_t)(uintptr_t)(nlr_lptr)lds_stage + __builtin_amdgcn_readfirstlane(wave) * (NLR_STAGE_FLOATS * 4u);  // uniform
+    auto stage_base = [&](uint32_t t) {
+        const uint32_t b = t * NLR_TILE + wave * 64;
+        return b + 64 <= P.M ? b : (P.M >= 64 ? P.M - 64 : 0);
+    };
+    auto stage_issue = [&](uint32_t t) {
+        const uint32_t b = __builtin_amdgcn_readfirstlane(stage_base(t));
+        const uint32_t l0 = stg_lds;
+        const uint32_t voff = (uint32_t)lane * 16u;
+        uint32_t keep;  // every statement saves and restores M0 itself: nothing is assumed about the code between them
+        const uint32_t np = P.F / 4;
+        for (uint32_t p = 0; p < np; ++p) {  // one piece = 64 samples x 16 B, contiguous in the piece-major feature buffer
+            const uint64_t g = reinterpret_cast<uint64_t>(P.feat) + ((uint64_t)p * P.M + b) * 16u;
+            asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[g]\n\ts_mov_b32 m0, %[k]"
+                         : [k] "=&s"(keep)
+                         : [v] "v"(voff), [l] "s"(l0 + p * 1024u), [g] "s"(g)
+                         : "memory");
+        }
+        {  // direction-encoding rows: lane i < 32 fetches the 16 bytes [n-tile i>>3][row block (i>>2)&1][q = i&3]
+            // (rows go by the tile's real sample numbers, not by the pulled-back feature window)
+            const uint32_t s0 = t * NLR_TILE + wave * 64 + 16u * ((uint32_t)lane >> 3 & 3u);
+            const uint32_t ray = (s0 < P.M ? s0 : P.M - 1) / P.S;
+            const uint64_t g = reinterpret_cast<uint64_t>(P.enc) + ((uint64_t)ray * 32u + 16u * ((lane >> 2) & 1) + 4u * (lane & 3)) * 4u;
+            uint64_t sv;
+            asm volatile(
+                "s_mov_b64 %[sv], exec\n\t"
+                "s_mov_b64 exec, %[lo32]\n\t"
+                "s_mov_b32 %[k], m0\n\t"
+                "s_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+                "global_load_lds_dwordx4 %[g], off\n\t"
+                "s_mov_b32 m0, %[k]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [sv] "=&s"(sv), [k] "=&s"(keep)
+                : [g] "v"(g), [l] "s"(l0 + NLR_STAGE_ENC * 4u), [lo32] "s"((uint64_t)0xffffffffull)
+                : "memory");
+        }
+        if constexpr (COMP) {  // per sample (lane i = sample i of the wave): t_k, t_k+1, |d| of its ray, "last sample of an opaque ray"
+            const uint32_t sm = t * NLR_TILE + wave * 64 + lane;
+            const uint32_t sc = sm < P.M ? sm : P.M - 1;
+            const uint32_t ray = sc / P.S, k = sc - ray * P.S;
+            const uint64_t g0 = reinterpret_cast<uint64_t>(P.tdist) + ((uint64_t)ray * (P.S + 1) + k) * 4u;
+            const uint64_t g2 = reinterpret_cast<uint64_t>(P.dnorm) + (uint64_t)ray * 4u;
+            asm volatile(
+                "s_mov_b32 %[k], m0\n\t"
+                "s_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+                "global_load_lds_dword %[g0], off\n\t"
+                "s_add_u32 m0, %[l], 0xfc\n\ts_nop 0\n\t"  // the instruction offset advances the LDS address too: 0xfc + 4 = 0x100
+                "global_load_lds_dword %[g0], off offset:4\n\t"
+                "s_add_u32 m0, %[l], 0x200\n\ts_nop 0\n\t"
+                "global_load_lds_dword %[g2], off\n\t"
+                "s_mov_b32 m0, %[k]"
+                : [k] "=&s"(keep)
+                : [g0] "v"(g0), [g2] "v"(g2), [l] "s"(l0 + NLR_STAGE_TD * 4u)
+                : "memory", "scc");
+            stg[NLR_STAGE_TD + 192 + lane] = (P.opaque && k == P.S - 1) ? 1.0f : 0.0f;
+        }
+    };
+    if (staged && blockIdx.x < ntiles) {
+        stage_issue(blockIdx.x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
 #ifdef NLR_STAMPS
     unsigned long long stamps[NLR_NSTAMP];
@@ -484,31 +608,40 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
 #ifdef NLR_STAMPS
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // ---- inputs of the wave's 64 samples: grid features as f32 units (row block J = 2t + jb holds features 16J + 4q + r),
-    // direction encoding of the sample's ray as one more 32-feature unit
-    Unit<2> fin[2][FT], encu[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
+    // ---- inputs of one 32-sample half: grid features as f32 units (row block J = 2t + jb holds features 16J + 4q + r) and the
+    // direction encoding of the sample's ray as one more 32-feature unit; read from the LDS staging area right before the half's
+    // trunk (or, outside the staged path, straight from global memory)
+    auto load_inputs = [&](auto hh, Unit<2> (&fin)[FT], Unit<2> &encu) {
+        constexpr int h = decltype(hh)::value;
+        const uint32_t bc = stage_base(tile);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const uint32_t smp = base + (2 * h + n) * 16 + col;
             const uint32_t sc = smp < P.M ? smp : P.M - 1;
+            const uint32_t idx = sc - bc;  // position inside the staged 64 samples
 #pragma unroll
             for (int t = 0; t < FT; ++t)
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) {
                     const uint32_t piece = 8 * t + 4 * jb + q;  // float4 index inside the feature row
                     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (4 * piece + 4 <= P.F)
-                        v = P.feat_piece_major ? *reinterpret_cast<const f32x4 *>(P.feat + ((size_t)piece * P.M + sc) * 4)
-                                               : *reinterpret_cast<const f32x4 *>(P.feat + (size_t)sc * P.F + 4 * piece);
-                    fin[h][t].a[jb][n] = v;
+                    if (4 * piece + 4 <= P.F) {
+                        if (staged) v = *reinterpret_cast<const f32x4 *>(stg + (piece * 64 + idx) * 4);
+                        else
+                            v = P.feat_piece_major ? *reinterpret_cast<const f32x4 *>(P.feat + ((size_t)piece * P.M + sc) * 4)
+                                                   : *reinterpret_cast<const f32x4 *>(P.feat + (size_t)sc * P.F + 4 * piece);
+                    }
+                    fin[t].a[jb][n] = v;
                 }
-            const uint32_t ray = sc / P.S;
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-                encu[h].a[jb][n] = P.rgb ? *reinterpret_cast<const f32x4 *>(P.enc + (size_t)ray * 32 + 16 * jb + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int jb = 0; jb < 2; ++jb) {
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (staged) v = *reinterpret_cast<const f32x4 *>(stg + NLR_STAGE_ENC + (((2 * h + n) * 2 + jb) * 4 + q) * 4);
+                else if (P.rgb) v = *reinterpret_cast<const f32x4 *>(P.enc + (size_t)(sc / P.S) * 32 + 16 * jb + 4 * q);
+                encu.a[jb][n] = v;
+            }
         }
+    };
 
     NLR_STAMP(1);  // input loads issued
     // per-sample outputs of one half: density, class probabilities, intensity (class-major / channel-major stores: the 16
@@ -561,12 +694,95 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         }
     };
 
+    // ---- compositing mode: per half, the heads' outputs are turned into one segment record by NHP small pieces of VALU work
+    struct HeadSt {
+        Unit<2> lo;
+        float raw[2], xr[2], ex[2], a[2], E[2], tp[2], wp[2], mx[2], sm[2], c[2];
+        float acc[2][4];   // [row block][r]
+    };
+    float wpall[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // segment-local weight of this lane's sample in each column tile (kept for the rgb sums)
+    constexpr int NHP = 35;
+    auto head_piece = [&](auto hh, auto ii, HeadSt &st) {
+        constexpr int h = decltype(hh)::value, I = decltype(ii)::value;
+        if constexpr (I < 2) {  // raw density of the column (row 0 sits on the q = 0 lanes) -> every lane of the column; exp
+            constexpr int n = I;
+            st.xr[n] = nlr_q_sum(q == 0 ? st.raw[n] : 0.0f) + P.density_bias;
+            st.ex[n] = expf(st.xr[n]);
+        } else if constexpr (I < 4) {  // softplus (models.py:1116), density out, sigma * delta (render.py:176-180)
+            constexpr int n = I - 2, g = 2 * h + n;
+            const float sp = st.xr[n] > 20.0f ? st.xr[n] : log1pf(st.ex[n]);
+            const uint32_t smp = base + g * 16 + col;
+            if (q == 0 && smp < P.M) P.density[smp] = sp;
+            const float *td = stg + NLR_STAGE_TD + 16 * g + col;  // staged t_k, t_k+1, |d|, last-sample flag of this lane's sample
+            float a = sp * ((td[64] - td[0]) * td[128]);
+            if (td[192] != 0.0f) a = INFINITY;  // opaque background: infinitely wide last interval
+            st.a[n] = a;
+        } else if constexpr (I == 4) {  // exclusive prefix of sigma*delta inside the segment (16-lane rows, then across the 2 tiles)
+            const float i0 = nlr_row_incl_scan(st.a[0]);
+            st.E[0] = nlr_row_shr1(i0);
+        } else if constexpr (I == 5) {
+            const float i1 = nlr_row_incl_scan(st.a[1]);
+            st.E[1] = nlr_row_shr1(i1) + nlr_row_sum(st.a[0]);
+        } else if constexpr (I < 8) {  // transmittance inside the segment
+            constexpr int n = I - 6;
+            st.tp[n] = expf(-st.E[n]);
+        } else if constexpr (I < 10) {  // alpha, segment-local weight
+            constexpr int n = I - 8;
+            st.wp[n] = (1.0f - expf(-st.a[n])) * st.tp[n];
+            wpall[2 * h + n] = st.wp[n];
+        } else if constexpr (I < 14) {  // softmax over rows [0,K): running maximum of the masked logits
+            constexpr int n = (I - 10) >> 1, jb = (I - 10) & 1;
+            if constexpr (jb == 0) st.mx[n] = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st.mx[n] = fmaxf(st.mx[n], (16 * jb + 4 * q + r) < (int)P.K ? st.lo.a[jb][n][r] : -INFINITY);
+        } else if constexpr (I < 16) {
+            constexpr int n = I - 14;
+            st.mx[n] = nlr_q_max(st.mx[n]);
+        } else if constexpr (I < 20) {  // sum of exp
+            constexpr int n = (I - 16) >> 1, jb = (I - 16) & 1;
+            if constexpr (jb == 0) st.sm[n] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st.sm[n] += (16 * jb + 4 * q + r) < (int)P.K ? __expf(st.lo.a[jb][n][r] - st.mx[n]) : 0.0f;
+        } else if constexpr (I < 22) {  // weight / softmax denominator
+            constexpr int n = I - 20;
+            st.sm[n] = nlr_q_sum(st.sm[n]);
+            st.c[n] = st.wp[n] / st.sm[n];
+        } else if constexpr (I < 26) {  // w' p_c (exp again: cheaper than 16 live registers) and w' intensity in the intensity row
+            constexpr int n = (I - 22) >> 1, jb = (I - 22) & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * jb + 4 * q + r;
+                const float x = st.lo.a[jb][n][r];
+                const float v = row == (int)P.int_row ? x * st.wp[n] : (row < (int)P.K ? __expf(x - st.mx[n]) * st.c[n] : 0.0f);
+                st.acc[jb][r] = n == 0 ? v : st.acc[jb][r] + v;
+            }
+        } else if constexpr (I < 34) {  // sum over the 16 samples of the row
+            constexpr int jb = ((I - 26) >> 2) & 1, r = (I - 26) & 3;
+            st.acc[jb][r] = nlr_row_sum(st.acc[jb][r]);
+        } else {  // lanes col < 8 of each row hold one value each: rows 16*(col>>2) + 4q + (col&3)
+            float v = st.acc[0][0];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col == 4 * jb + r) v = st.acc[jb][r];
+            const uint32_t s0 = base + 32 * h;
+            if (col < 8 && s0 < P.M) P.seg[(size_t)(s0 >> 5) * 32 + 16 * (col >> 2) + 4 * q + (col & 3)] = v;
+        }
+    };
+    // one piece every HSTEP steps of view layer 0 of the same half (the layer with the fewest live registers)
+    constexpr int SV0 = WT * (BW + 1) * 2;
+    constexpr int HSTEP = SV0 / NHP;
+    static_assert(!COMP || HSTEP >= 1, "not enough steps for the compositing pieces");
+
     if constexpr (!VIEW_F32) {
         // =================================================== bf16 view MLP ===================================================
         BT<4> hbe[BW + 1];  // [bottleneck | dir-enc] k-blocks of both halves (column tiles 2h, 2h+1 belong to half h)
-        auto trunk = [&](auto hh) {
+        Unit<2> fin[FT], encu[2];
+        auto trunk = [&](auto hh, Unit<2> &lo_out, float (&raw_out)[2]) {
             constexpr int h = decltype(hh)::value;
-            constexpr int F0 = h * FR_T;
+            constexpr int F0 = h * FR_HALF;
+            load_inputs(hh, fin, encu[h]);
             float raw[2] = {0.0f, 0.0f};
             Unit<2> lo;
 #pragma unroll
@@ -577,7 +793,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 // ---- density trunk + heads on split-bf16
                 BT<2> fh[FT], fl[FT];
 #pragma unroll
-                for (int t = 0; t < FT; ++t) nlr_split_all<false, 0>(fh[t], fl[t], fin[h][t]);
+                for (int t = 0; t < FT; ++t) nlr_split_all<false, 0>(fh[t], fl[t], fin[t]);
                 if constexpr (h == 0) NLR_STAMP(2);  // features split
                 BT<2> dh[2], dl[2];
                 nlr_gemm<2, FT, 2, 2, 2, F0, 8>(
@@ -643,7 +859,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                     tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D0 + 32 * decltype(o)::value, b); },
                     [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
                         constexpr int G = decltype(g)::value, J = decltype(j)::value;
-                        nlr_mma_f32<G == 0>(u.a[J], bj, f0, fin[h][G >> 1].a[G & 1]);
+                        nlr_mma_f32<G == 0>(u.a[J], bj, f0, fin[G >> 1].a[G & 1]);
                     },
                     [&](auto o, auto, const Unit<2> &u) {
                         hid[decltype(o)::value] = u;
@@ -687,27 +903,39 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 }
             }
             if constexpr (h == 0) NLR_STAMP(6);  // H2
-            heads_out(hh, raw, lo);
+            if constexpr (COMP) {
+                lo_out = lo;
+                raw_out[0] = raw[0];
+                raw_out[1] = raw[1];
+            } else {
+                heads_out(hh, raw, lo);
+            }
             if constexpr (h == 0) NLR_STAMP(7);  // softmax + stores of half A
         };
-        trunk(ic<0>{});
-        trunk(ic<1>{});
-        NLR_STAMP(8);  // trunk + heads of half B
+        Unit<2> hlo;
+        float hraw[2] = {0.0f, 0.0f};
         if (P.rgb == nullptr) {  // density / semantic / intensity only (uniform for the whole grid)
-            nlr_pad<F_VIEW % NLR_CHUNK_FRAGS>(tp);
+            trunk(ic<0>{}, hlo, hraw);
+            nlr_skip<FR_T, FR_V0 + FR_V1>(tp);
+            trunk(ic<1>{}, hlo, hraw);
+            nlr_skip<FR_HALF + FR_T, FR_V0 + FR_V1>(tp);
+            nlr_pad<F_HID % NLR_CHUNK_FRAGS>(tp);
             continue;
         }
         // ---- view MLP.  Layer 0 input = [bottleneck | enc]; layer 1 input = [x | bottleneck | enc] (skip concat,
         // models.py:1227-1228); the 27 dir-encoding features ride as one extra zero-padded 32-feature k-block.
-        nlr_pack_all<false, 0>(hbe[BW], encu[0]);
-        nlr_pack_all<false, 2>(hbe[BW], encu[1]);
         BT<4> x[WT], y[WT];
         Unit<2> cyh[2];
         // The last output unit of every layer is carried raw and packed behind the MFMAs of the next layer's first unit, whose
         // first k-groups do not read it.
         auto view01 = [&](auto hh) {
             constexpr int h = decltype(hh)::value;
-            constexpr int F0 = F_VIEW + h * (FR_V0 + FR_V1);
+            constexpr int F0 = h * FR_HALF + FR_T;
+            HeadSt hst;  // (COMP) the half's heads, consumed piece by piece behind layer 0
+            hst.lo = hlo;
+            hst.raw[0] = hraw[0];
+            hst.raw[1] = hraw[1];
+            nlr_pack_all<false, 2 * h>(hbe[BW], encu[h]);
             Unit<2> cx;
             nlr_gemm_pipe<WT, BW + 1, 2, 2, F0, 8, 0, 1, true>(
                 tp, cx, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_V0 + 32 * decltype(o)::value, b); },
@@ -715,7 +943,11 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                     constexpr int G = decltype(g)::value, J = decltype(j)::value;
                     nlr_mma_bf16<G == 0, 2 * h>(u.a[J], bj, f0, hbe[G]);
                 },
-                [&](auto o, auto p, const Unit<2> &u) { nlr_pack_piece<true, decltype(p)::value, 2 * h>(x[decltype(o)::value], u); }, nop);
+                [&](auto o, auto p, const Unit<2> &u) { nlr_pack_piece<true, decltype(p)::value, 2 * h>(x[decltype(o)::value], u); }, nop,
+                [&](auto st) {
+                    constexpr int IDX = decltype(st)::value;
+                    if constexpr (COMP && IDX % HSTEP == HSTEP / 2 && IDX / HSTEP < NHP) head_piece(hh, ic<IDX / HSTEP>{}, hst);
+                });
             nlr_gemm_pipe<WT, WT + BW + 1, 2, 2, F0 + FR_V0, 8, 8, (WT - 1) * 2, true>(
                 tp, cyh[h], [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_V1 + 32 * decltype(o)::value, b); },
                 [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
@@ -726,10 +958,17 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 [&](auto o, auto p, const Unit<2> &u) { nlr_pack_piece<true, decltype(p)::value, 2 * h>(y[decltype(o)::value], u); },
                 [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 2 * h>(x[WT - 1], cx); });
         };
+        trunk(ic<0>{}, hlo, hraw);
+        NLR_STAMP(8);  // (unused)
         view01(ic<0>{});
         NLR_STAMP(9);  // V0 + V1 of half A
+        trunk(ic<1>{}, hlo, hraw);
         view01(ic<1>{});
-        NLR_STAMP(10);  // V0 + V1 of half B
+        NLR_STAMP(10);  // trunk + heads + V0 + V1 of half B
+        if (staged) {  // every staged input of this tile has been read: request the next tile's (lands under the hidden layers)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (tile + gridDim.x < ntiles) stage_issue(tile + gridDim.x);
+        }
         // hidden layers 2..depth-1 at full width (4 MFMAs per tape fragment), two per iteration (y -> x -> y) so that no
         // tile copies are needed.  The pending last unit of layer 1 is the concatenation of the two halves' units.
         Unit<4> cx4, cy4;
@@ -790,7 +1029,28 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 [&](auto p) { nlr_pack_piece<true, decltype(p)::value, 0>(y[WT - 1], cy4); });
         }
         NLR_STAMP(12);  // rgb layer
-        if (q == 0) {  // rows 0..2 of the output unit sit on lanes 0..15
+        if constexpr (COMP) {  // sum over the segment of w' rgb -> slots 29..31 of the segment record
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float sum[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float z = P.rgb_premul * out1.a[0][2 * h + n][c] + P.rgb_bias;
+                        const float sg = 1.0f / (1.0f + expf(-z));
+                        sum[c] += (sg * (1.0f + 2.0f * P.rgb_padding) - P.rgb_padding) * wpall[2 * h + n];
+                    }
+                float v = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    sum[c] = nlr_row_sum(sum[c]);
+                    if (col == c) v = sum[c];
+                }
+                const uint32_t s0 = base + 32 * h;
+                if (q == 0 && col < 3 && s0 < P.M) P.seg[(size_t)(s0 >> 5) * 32 + 29 + col] = v;
+            }
+        } else if (q == 0) {  // rows 0..2 of the output unit sit on lanes 0..15
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const uint32_t smp = base + n * 16 + col;
@@ -819,6 +1079,8 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         // =================================================== exact-f32 chain: each half runs the whole tape ======================
         auto pass = [&](auto hh) {
             constexpr int h = decltype(hh)::value;
+            Unit<2> fin[FT], encu1;
+            load_inputs(hh, fin, encu1);
             float raw[2] = {0.0f, 0.0f};
             Unit<2> lo;
 #pragma unroll
@@ -830,7 +1092,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_D0 + 32 * decltype(o)::value, b); },
                 [&](Unit<2> &u, auto g, auto j, const uint4 &f0, const uint4 &, const f32x4 &bj) {
                     constexpr int G = decltype(g)::value, J = decltype(j)::value;
-                    nlr_mma_f32<G == 0>(u.a[J], bj, f0, fin[h][G >> 1].a[G & 1]);
+                    nlr_mma_f32<G == 0>(u.a[J], bj, f0, fin[G >> 1].a[G & 1]);
                 },
                 [&](auto o, auto, const Unit<2> &u) {
                     hid[decltype(o)::value] = u;
@@ -876,7 +1138,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 nlr_pad<FR_T % NLR_CHUNK_FRAGS>(tp);
                 return;
             }
-            hb[BW] = encu[h];
+            hb[BW] = encu1;
             Unit<2> x[WT], y[WT];
             nlr_gemm<WT, 2 * (BW + 1), 2, 2, 1, FR_T, 1>(
                 tp, [&](auto o, f32x4(&b)[2]) { bias_rows(lds_bias + OB_V0 + 32 * decltype(o)::value, b); },
@@ -947,9 +1209,9 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
 }
 
 
-// One explicit instance per translation unit (nlr_mlp_inst.hip is compiled once per (WT, HT, PREC) by the Makefile:
+// One explicit instance per translation unit (nlr_mlp_inst.hip is compiled once per (WT, HT, PREC, COMP) by the Makefile:
 // the fully unrolled GEMM chain is slow to compile, so the instances build in parallel).
-#define NLR_MLP_LAUNCH_NAME2(wt, ht, pr) nlr_mlp_launch_##wt##_##ht##_##pr
-#define NLR_MLP_LAUNCH_NAME(wt, ht, pr) NLR_MLP_LAUNCH_NAME2(wt, ht, pr)
-#define NLR_MLP_DECLARE(wt, ht, pr) void NLR_MLP_LAUNCH_NAME(wt, ht, pr)(const MlpParams &P, dim3 grid, hipStream_t st)
+#define NLR_MLP_LAUNCH_NAME2(wt, ht, pr, cm) nlr_mlp_launch_##wt##_##ht##_##pr##_##cm
+#define NLR_MLP_LAUNCH_NAME(wt, ht, pr, cm) NLR_MLP_LAUNCH_NAME2(wt, ht, pr, cm)
+#define NLR_MLP_DECLARE(wt, ht, pr, cm) void NLR_MLP_LAUNCH_NAME(wt, ht, pr, cm)(const MlpParams &P, dim3 grid, hipStream_t st)
 

@@ -1,0 +1,101 @@
+// Microbenchmark (diagnostic, round 2): does the ~10-cycle cost of the 1 KiB fragment read beside v_mfma_f32_16x16x32_bf16 (mfma_shape3)
+// depend on WHERE the fragment lands?  Same loop as mfma_shape3 variant 4 (4 MFMAs per fragment, 8-deep ring), hand-placed in asm:
+//   0: fragments -> VGPRs, accumulators in VGPRs        1: fragments -> AGPRs (ds_read_b128 a[..]), MFMA A operand from AGPRs, acc VGPR
+//   2: fragments -> VGPRs, accumulators in AGPRs        3: fragments -> AGPRs, accumulators in AGPRs
+//   4: as 0 without the LDS reads (floor)
+// hipcc --offload-arch=gfx950 -O3 -o mfma_shape4 mfma_shape4.hip && ./mfma_shape4
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+#include <string.h>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define FRAGS 64
+#define STEP(FC, AC, RD, R, B0, B1, B2, B3)                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(7)\n\t"                                                                        \
+                 "v_mfma_f32_16x16x32_bf16 %[c0], %[f], %[b0], %[c0]\n\t"                                          \
+                 "v_mfma_f32_16x16x32_bf16 %[c1], %[f], %[b1], %[c1]\n\t"                                          \
+                 "v_mfma_f32_16x16x32_bf16 %[c2], %[f], %[b2], %[c2]\n\t"                                          \
+                 "v_mfma_f32_16x16x32_bf16 %[c3], %[f], %[b3], %[c3]\n\t" RD                                       \
+                 : [f] "+" FC(R), [c0] "+" AC(acc0), [c1] "+" AC(acc1), [c2] "+" AC(acc2), [c3] "+" AC(acc3) \
+                 : [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [ad] "v"(addr) \
+                 : "memory")
+template <int V>
+__global__ void __launch_bounds__(256, 1) k(const uint4 *__restrict__ w, const uint4 *__restrict__ xin, float *out, int steps,
+                                          unsigned long long *clk) {
+    __shared__ __align__(16) uint4 lds[FRAGS * 64 + 2560];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < FRAGS * 64; i += 256) lds[i] = w[i];
+    __syncthreads();
+    bf16x8 b[16];
+    for (int i = 0; i < 16; ++i) b[i] = __builtin_bit_cast(bf16x8, xin[(blockIdx.x * 256 + threadIdx.x) * 16 + i]);
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    u32x4 q0, q1, q2, q3, q4, q5, q6, q7;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds + lane * 16;
+    // prime the queue: 8 reads outstanding
+#define PRIME(R, F)                                                                                          \
+    {                                                                                                        \
+        const uint32_t addr = lbase + F * 1024;                                                              \
+        if (V == 1 || V == 3) asm volatile("ds_read_b128 %0, %1" : "=a"(R) : "v"(addr) : "memory");           \
+        else asm volatile("ds_read_b128 %0, %1" : "=v"(R) : "v"(addr) : "memory");                            \
+    }
+    PRIME(q0, 0) PRIME(q1, 1) PRIME(q2, 2) PRIME(q3, 3) PRIME(q4, 4) PRIME(q5, 5) PRIME(q6, 6) PRIME(q7, 7)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int s = 0; s < steps; s += 16) {
+#define ONE(U, R)                                                                                                          \
+    {                                                                                                                          \
+        const uint32_t addr = lbase + ((s + U + 8) & (FRAGS - 1)) * 1024;                                                      \
+        if (V == 0) STEP("v", "v", "ds_read_b128 %[f], %[ad]", R, b[U], b[(U + 5) & 15], b[(U + 3) & 15], b[(U + 9) & 15]);   \
+        else if (V == 1) STEP("a", "v", "ds_read_b128 %[f], %[ad]", R, b[U], b[(U + 5) & 15], b[(U + 3) & 15], b[(U + 9) & 15]); \
+        else if (V == 2) STEP("v", "a", "ds_read_b128 %[f], %[ad]", R, b[U], b[(U + 5) & 15], b[(U + 3) & 15], b[(U + 9) & 15]); \
+        else if (V == 3) STEP("a", "a", "ds_read_b128 %[f], %[ad]", R, b[U], b[(U + 5) & 15], b[(U + 3) & 15], b[(U + 9) & 15]); \
+        else STEP("v", "v", "s_nop 0", R, b[U], b[(U + 5) & 15], b[(U + 3) & 15], b[(U + 9) & 15]);                           \
+    }
+        ONE(0, q0) ONE(1, q1) ONE(2, q2) ONE(3, q3) ONE(4, q4) ONE(5, q5) ONE(6, q6) ONE(7, q7)
+        ONE(8, q0) ONE(9, q1) ONE(10, q2) ONE(11, q3) ONE(12, q4) ONE(13, q5) ONE(14, q6) ONE(15, q7)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float r = 0;
+    for (int i = 0; i < 4; ++i) r += acc0[i] + acc1[i] + acc2[i] + acc3[i];
+    r += (float)(q0[0] + q1[0] + q2[0] + q3[0] + q4[0] + q5[0] + q6[0] + q7[0]);
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if (threadIdx.x == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+#define NV 5
+int main() {
+    const int blocks = 256, steps = 1 << 18;
+    std::vector<uint16_t> h((size_t)FRAGS * 64 * 8), hx((size_t)blocks * 256 * 16 * 8);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; float f = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; uint32_t u; memcpy(&u, &f, 4); return (uint16_t)(u >> 16); };
+    for (auto &v : h) v = rnd();
+    for (auto &v : hx) v = rnd();
+    uint4 *w, *x; float *out; unsigned long long *clk;
+    hipMalloc(&w, h.size() * 2); hipMalloc(&x, hx.size() * 2); hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, blocks * 16);
+    hipMemcpy(w, h.data(), h.size() * 2, hipMemcpyHostToDevice); hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+    const char *names[NV] = {"0: frag VGPR, acc VGPR", "1: frag AGPR, acc VGPR", "2: frag VGPR, acc AGPR", "3: frag AGPR, acc AGPR", "4: no LDS reads (floor)"};
+    for (int rep = 0; rep < 2; ++rep)
+        for (int v = 0; v < NV; ++v) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            for (int warm = 0; warm < 6; ++warm) {
+                hipEventRecord(a);
+                switch (v) {
+                    case 0: hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, w, x, out, steps, clk); break;
+                    case 1: hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, w, x, out, steps, clk); break;
+                    case 2: hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, w, x, out, steps, clk); break;
+                    case 3: hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, w, x, out, steps, clk); break;
+                    default: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, w, x, out, steps, clk); break;
+                }
+                hipEventRecord(b); hipEventSynchronize(b);
+            }
+            float ms; hipEventElapsedTime(&ms, a, b);
+            unsigned long long hc[512]; hipMemcpy(hc, clk, sizeof(hc), hipMemcpyDeviceToHost);
+            double mhz = 0; for (int i = 0; i < blocks; ++i) mhz += (double)hc[2 * i] / (double)hc[2 * i + 1] * 100.0; mhz /= blocks;
+            const double flop = (double)blocks * 4 * steps * 32768.0 * 2.0;
+            printf("%-28s %.3f ms, %.0f TFLOP/s, in-kernel clock %.0f MHz, %.1f cycles per fragment (4 MFMAs)\n", names[v], ms, flop / ms / 1e9, mhz,
+                   (double)hc[0] / steps);
+        }
+    return 0;
+}

@@ -340,6 +340,39 @@ def test_model_forward(name, precision):
         gate("rgb", npy(r["rgb"]), g["out_rgb"], 2e-3, 3e-2)  # bf16 view MLP: 8 mantissa bits per layer, 8 layers
 
 
+@pytest.mark.parametrize("name", _names("fwd_"))
+def test_render_path_compositing_mode(name):
+    """The render path proper (no ray_history: NLR_PREC_FAST, the MLP kernel composites inside 32-sample segments and
+    nlr_composite_kernel combines the segment records) against the reference run, at the gates of test_model_forward; and
+    against the ray_history path of the same library (same weights bit for bit, value sums to 2e-6)."""
+    g = golden(name)
+    mc, sd, model = _model(g, _lib.PREC_FAST)
+    batch_np = nlidar.synthetic_sweep(width=int(g["width"]), seed=int(g["seed"]), beams=list(g["beams"]))
+    batch = {k: cu(v) for k, v in batch_np.items()}
+    r, _ = model.render_rays(batch, scale_factor=1 / 250)
+    ru, _ = model.render_rays(batch, scale_factor=1 / 250, want_history=True)
+
+    def gate(name, got, ref, mean_tol, max_tol):
+        d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
+        assert d.mean() <= mean_tol and d.max() <= max_tol, f"{name}: mean {d.mean():.3e} (<= {mean_tol}), max {d.max():.3e} (<= {max_tol})"
+
+    gate("depth", npy(r["depth"]), g["out_depth"], 1e-3, 1e-2)
+    assert np.percentile(np.abs(npy(r["depth"]) - g["out_depth"]), 95) <= 1e-3
+    gate("acc", npy(r["acc"]), g["out_acc"], 1e-6, 1e-5)
+    if "out_intensity" in g:
+        gate("intensity", npy(r["intensity"]), g["out_intensity"], 1e-4, 1e-3)
+    if "out_semantic" in g:
+        gate("semantic", npy(r["semantic"]), g["out_semantic"], 1e-4, 3e-2)
+        np.testing.assert_array_equal(npy(r["labels"]), g["out_semantic"].argmax(-1))  # bit-exact labels
+    gate("rgb", npy(r["rgb"]), g["out_rgb"], 2e-3, 3e-2)
+    for k in ("depth", "acc", "distance_median", "points"):
+        np.testing.assert_array_equal(npy(r[k]), npy(ru[k]))
+    for k in ("rgb", "semantic", "intensity"):
+        if k in r:
+            np.testing.assert_allclose(npy(r[k]), npy(ru[k]), rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(npy(r["labels"]), npy(ru["labels"]))
+
+
 def test_camera_forward_c3():
     """BASELINE config 3 (camera novel view, hierarchical 64 + 128): orthonormal image-plane bases, per-ray radii."""
     from nerflidar_hip import camera as ncamera
@@ -412,9 +445,16 @@ def test_full_size_properties():
     batch = {k: cu(v) for k, v in batch_np.items()}
     r1, h1 = model.render_rays(batch, want_history=True)
     r2, _ = model.render_rays(batch)
+    r3, _ = model.render_rays(batch)
     torch.cuda.synchronize()
     for k in r2:
-        np.testing.assert_array_equal(npy(r1[k]), npy(r2[k]))  # no atomics on the forward path: deterministic
+        np.testing.assert_array_equal(npy(r2[k]), npy(r3[k]))  # no atomics on the forward path: deterministic
+    # with ray_history the per-sample heads go to HBM and nlr_composite_kernel sums them; without, the MLP kernel composites
+    # inside its 32-sample segments (compositing mode): same weights, depth and acc bit for bit, the value sums in another order
+    for k in ("depth", "acc", "distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
+        np.testing.assert_array_equal(npy(r1[k]), npy(r2[k]))
+    for k in ("rgb", "semantic", "intensity"):
+        np.testing.assert_allclose(npy(r1[k]), npy(r2[k]), rtol=0, atol=2e-6)
     for h in h1:
         s, w = npy(h["sdist"]), npy(h["weights"])
         assert (np.diff(s, axis=-1) >= 0).all() and s.min() >= 0 and s.max() <= 1
