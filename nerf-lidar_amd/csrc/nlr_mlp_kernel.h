@@ -153,7 +153,9 @@ struct Tape {
         for (int f = 0; f < NLR_PF; ++f) ring[f] = buf(0)[f * 64 + lane];
     }
     // bookkeeping at fragment position F of the current chunk; returns the fragment (raw 16 bytes per lane).
-    template <int F>
+    // IGNORED: a padding step - the fragment at F is not used, and neither is any fragment before the next chunk boundary, so
+    // the read-ahead only has to resume where it reaches into the next chunk
+    template <int F, bool IGNORED = false>
     __device__ __forceinline__ uint4 step() {
         static_assert(F >= 0 && F < NLR_CHUNK_FRAGS, "tape position");
         if constexpr (F == NLR_SIG_F) signal();
@@ -163,8 +165,11 @@ struct Tape {
             dma(b2);
         }
         const uint4 a = ring[F % NLR_PF];
-        if constexpr (F + NLR_PF < NLR_CHUNK_FRAGS) ring[F % NLR_PF] = buf(b0)[(F + NLR_PF) * 64 + lane];
-        else ring[F % NLR_PF] = buf(b1)[(F + NLR_PF - NLR_CHUNK_FRAGS) * 64 + lane];
+        if constexpr (F + NLR_PF < NLR_CHUNK_FRAGS) {
+            if constexpr (!IGNORED) ring[F % NLR_PF] = buf(b0)[(F + NLR_PF) * 64 + lane];
+        } else {
+            ring[F % NLR_PF] = buf(b1)[(F + NLR_PF - NLR_CHUNK_FRAGS) * 64 + lane];
+        }
         if constexpr (F == NLR_CHUNK_FRAGS - 1) {
             ++cur;
             const int t = b0;
@@ -186,7 +191,7 @@ using ic = std::integral_constant<int, I>;
 template <int F>
 __device__ __forceinline__ void nlr_pad(Tape &tp) {
     if constexpr (F % NLR_CHUNK_FRAGS != 0) {
-        (void)tp.template step<F % NLR_CHUNK_FRAGS>();
+        (void)tp.template step<F % NLR_CHUNK_FRAGS, true>();
         __builtin_amdgcn_sched_barrier(0);
         nlr_pad<F % NLR_CHUNK_FRAGS + 1>(tp);
     }
@@ -643,7 +648,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         }
     };
 
-    NLR_STAMP(1);  // input loads issued
+    NLR_STAMP(1);  // (tile prologue)
     // per-sample outputs of one half: density, class probabilities, intensity (class-major / channel-major stores: the 16
     // lanes of a row write 64 consecutive bytes)
     auto heads_out = [&](auto hh, const float (&raw)[2], const Unit<2> &lo) {
@@ -725,10 +730,10 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
             st.E[1] = nlr_row_shr1(i1) + nlr_row_sum(st.a[0]);
         } else if constexpr (I < 8) {  // transmittance inside the segment
             constexpr int n = I - 6;
-            st.tp[n] = expf(-st.E[n]);
+            st.tp[n] = __expf(-st.E[n]);  // (v_exp_f32: these weights only scale the value sums; the stored density keeps libm)
         } else if constexpr (I < 10) {  // alpha, segment-local weight
             constexpr int n = I - 8;
-            st.wp[n] = (1.0f - expf(-st.a[n])) * st.tp[n];
+            st.wp[n] = (1.0f - __expf(-st.a[n])) * st.tp[n];
             wpall[2 * h + n] = st.wp[n];
         } else if constexpr (I < 14) {  // softmax over rows [0,K): running maximum of the masked logits
             constexpr int n = (I - 10) >> 1, jb = (I - 10) & 1;
@@ -1038,7 +1043,7 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float z = P.rgb_premul * out1.a[0][2 * h + n][c] + P.rgb_bias;
-                        const float sg = 1.0f / (1.0f + expf(-z));
+                        const float sg = __frcp_rn(1.0f + __expf(-z));
                         sum[c] += (sg * (1.0f + 2.0f * P.rgb_padding) - P.rgb_padding) * wpall[2 * h + n];
                     }
                 float v = 0.0f;

@@ -17,8 +17,8 @@ raw = np.zeros(1024 * NS, np.uint64)
 L = _lib.lib()
 assert L.nlr_debug_stamps(raw.ctypes.data_as(C.c_void_p), C.c_size_t(raw.size)) == 0
 raw = raw.reshape(1024, NS)[:256].astype(np.int64)
-names = ["input loads issued", "feature split (half A)", "D0 (A)", "D2 (A)", "H1 (A)", "H2 (A)", "softmax + stores (A)", "trunk + heads (B)",
-         "V0 + V1 (A)", "V0 + V1 (B)", "hidden layer pairs", "rgb layer", "rgb stores", "tape padding"]
+names = ["input reads (half A)", "feature split (A)", "D0 (A)", "D2 (A)", "H1 (A)", "H2 (A)", "heads out / hand-over (A)", "-",
+         "V0 + V1 (A) [+ compositing pieces]", "trunk + heads + V0 + V1 (B)", "hidden layer pairs", "rgb layer", "rgb tail", "tape padding"]
 d = np.diff(raw[:, :15], axis=1)
 ok = (d >= 0).all(1) & (d < 10**7).all(1) & (raw[:, 0] > 0)
 clk = (raw[:, 14] - raw[:, 0]) / np.maximum(raw[:, 23] - raw[:, 22], 1) * 100.0
