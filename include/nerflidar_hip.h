@@ -174,6 +174,10 @@ typedef struct NlrLevelOut {         /* one ray_history entry (models.py:553-557
     float *semantic;                 /* class-major [class_num, N, S] probabilities (final level) */
     float *intensity;                /* [N, S] (final level) */
     float *depth;                    /* [N] per-level rendering['depth'] */
+    /* the rest of the level's `rendering` dict (ZI/models.py:514-531) for the levels before the last (whose rendering is
+     * NlrOut itself): proposal MLPs return rgb = 0, so r_rgb is the background seen through the level's weights */
+    float *r_rgb;                    /* [N,3] */
+    float *r_acc, *r_distance_mean, *r_distance_median, *r_distance_percentile_5, *r_distance_percentile_95; /* [N] */
 } NlrLevelOut;
 
 typedef struct NlrOut {              /* renderings[-1] (render.py:219-284); any may be NULL */

@@ -227,12 +227,15 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     if (lv.W % 32 || lv.WB % 32) NLR_FAIL(NLR_ERR_UNSUPPORTED, "view MLP: widths must be multiples of 32");
     if (lv.F % 4) NLR_FAIL(NLR_ERR_UNSUPPORTED, "NerfMLP: L*C = %u must be a multiple of 4", lv.F);
     if ((rc = check_linear(d.density2, lv.WB, 64, "density_layer.2"))) return rc;
+    // use_semantic with no_sem_layer (models.py:1133): the logits are channels [1, 1+K) of the bottleneck.  They reach the
+    // softmax through the same two head GEMMs as a learned sem_layer, with pass-through weights that are exact in the
+    // split-bf16 / f32 arithmetic: hidden rows c and 32 + c hold relu(+x_{1+c}) and relu(-x_{1+c}), output row c their difference.
     const bool sem_layer = d.use_semantic && !d.no_sem_layer;
-    if (d.use_semantic && d.no_sem_layer)
-        NLR_FAIL(NLR_ERR_UNSUPPORTED, "use_semantic with no_sem_layer=True (semantic = bottleneck[1:1+K]) has no fused path yet");
-    lv.K = sem_layer ? d.class_num : 0;
+    const bool sem_pass = d.use_semantic && d.no_sem_layer;
+    if (sem_pass) NLR_CHECK_ARG(d.class_num <= 32 && 1 + d.class_num <= d.bottleneck_width, "no_sem_layer: class_num %u does not fit", d.class_num);
+    lv.K = d.use_semantic ? d.class_num : 0;
     lv.use_int = d.use_intensity != 0;
-    lv.HT = (sem_layer ? 2 : 0) + (lv.use_int ? 2 : 0);
+    lv.HT = (d.use_semantic ? 2 : 0) + (lv.use_int ? 2 : 0);
     NLR_CHECK_ARG(lv.K + (lv.use_int ? 1 : 0) <= 32, "class_num %u (+intensity) exceeds one 32-row output tile", lv.K);
 
     lv.prec = prec;
@@ -267,6 +270,15 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
             for (uint32_t r = 0; r < d.class_num; ++r) {
                 for (uint32_t c = 0; c < 64; ++c) h2.at(r, r0 + c) = d.sem2.weight[(size_t)r * 64 + c];
                 b2[r] = d.sem2.bias[r];
+            }
+            r0 += 64;
+        }
+        if (sem_pass) {
+            for (uint32_t c = 0; c < d.class_num; ++c) {
+                h1.at(r0 + c, 1 + c) = 1.0f;
+                h1.at(r0 + 32 + c, 1 + c) = -1.0f;
+                h2.at(c, r0 + c) = 1.0f;
+                h2.at(c, r0 + 32 + c) = -1.0f;
             }
             r0 += 64;
         }
@@ -619,10 +631,22 @@ extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t 
             if (fuse)
                 rc = nlr_composite_segments(density, tdist, rays->directions, seg, lv.K, lv.use_int ? 1 : 0, rays->far, rays->origins, N, S,
                                             (int)m->opaque, m->bg, (int)cfg->compute_extras, cfg->scale_factor, weights, out, ho.depth, st);
-            else
-                rc = nlr_composite_level(density, tdist, rays->directions, last ? rgb : nullptr, last ? sem : nullptr, last ? inten : nullptr,
-                                         rays->far, rays->origins, N, S, lv.K, (int)m->opaque, m->bg, last ? (int)cfg->compute_extras : 0,
-                                         last ? cfg->scale_factor : 0.0f, weights, last ? out : nullptr, ho.depth, st);
+            else if (last)
+                rc = nlr_composite_level(density, tdist, rays->directions, rgb, sem, inten, rays->far, rays->origins, N, S, lv.K,
+                                         (int)m->opaque, m->bg, (int)cfg->compute_extras, cfg->scale_factor, weights, out, ho.depth, st);
+            else {  // a level before the last: weights for the next resampling, its depth, and (on request) the rest of its rendering
+                NlrOut lo;
+                memset(&lo, 0, sizeof(lo));
+                lo.rgb = ho.r_rgb;
+                lo.acc = ho.r_acc;
+                lo.distance_mean = ho.r_distance_mean;
+                lo.distance_median = ho.r_distance_median;
+                lo.distance_percentile_5 = ho.r_distance_percentile_5;
+                lo.distance_percentile_95 = ho.r_distance_percentile_95;
+                const bool extras = cfg->compute_extras && (lo.distance_mean || lo.distance_median || lo.distance_percentile_5 || lo.distance_percentile_95);
+                rc = nlr_composite_level(density, tdist, rays->directions, nullptr, nullptr, nullptr, rays->far, rays->origins, N, S, 0,
+                                         (int)m->opaque, m->bg, extras ? 1 : 0, 0.0f, weights, &lo, ho.depth, st);
+            }
         }
         if (rc) return rc;
         prev_s = sdist;

@@ -39,7 +39,8 @@ int nlr_launch_direnc(const DirEncParams &P, hipStream_t st) {
 // silently emulated.  X(view width / 32, head units of 32, precision, compositing mode)
 #define NLR_FOR_ALL_INSTANCES(X) \
     X(8, 4, 0, 0) X(8, 4, 1, 0) X(8, 4, 2, 0) X(8, 4, 2, 1) X(8, 2, 0, 0) X(8, 2, 1, 0) X(8, 2, 2, 0) X(8, 2, 2, 1) \
-    X(4, 2, 0, 0) X(4, 2, 1, 0) X(4, 2, 2, 0) X(4, 2, 2, 1)
+    X(8, 0, 0, 0) X(8, 0, 1, 0) X(8, 0, 2, 0) X(8, 0, 2, 1) X(4, 4, 0, 0) X(4, 4, 1, 0) X(4, 4, 2, 0) X(4, 4, 2, 1) \
+    X(4, 2, 0, 0) X(4, 2, 1, 0) X(4, 2, 2, 0) X(4, 2, 2, 1) X(4, 0, 0, 0) X(4, 0, 1, 0) X(4, 0, 2, 0) X(4, 0, 2, 1)
 #define NLR_DECL(wt, ht, pr, cm) NLR_MLP_DECLARE(wt, ht, pr, cm);
 NLR_FOR_ALL_INSTANCES(NLR_DECL)
 #undef NLR_DECL
@@ -86,6 +87,6 @@ int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uin
     }
     NLR_FAIL(NLR_ERR_UNSUPPORTED,
              "NerfMLP shape (width %u, bottleneck %u, %u grid features, %u head tiles, precision %u) has no fused kernel "
-             "instance; built: (width 256, sem+intensity), (width 256, sem), (width 128, sem), bottleneck 256, 33..64 grid features",
+             "instance; built: view widths 128 and 256 with 0, 1 or 2 heads (semantic / intensity), bottleneck 256, 33..64 grid features",
              W, WB, P.F, HT, prec);
 }

@@ -57,7 +57,8 @@ class NlrRenderCfg(C.Structure):
 
 
 class NlrLevelOut(C.Structure):
-    _fields_ = [(k, c_fp) for k in ("sdist", "tdist", "weights", "density", "rgb", "semantic", "intensity", "depth")]
+    _fields_ = [(k, c_fp) for k in ("sdist", "tdist", "weights", "density", "rgb", "semantic", "intensity", "depth", "r_rgb", "r_acc",
+                                    "r_distance_mean", "r_distance_median", "r_distance_percentile_5", "r_distance_percentile_95")]
 
 
 class NlrOut(C.Structure):

@@ -150,6 +150,21 @@ def workload(name: str, log2_hashmap: Optional[int] = None) -> ModelConfig:
         mc = ModelConfig(num_prop_samples=(64,), num_nerf_samples=128, num_levels=2,
                          prop_desired_grid_size=(512,),
                          nerf_mlp=MLPConfig(net_depth_viewdirs=8, net_width_viewdirs=256))
+    # --- parity cases for the parameter space of ZI/models.py:MLP beyond the named configurations
+    elif name == "P_NOSEM":  # no semantic / intensity head at all (Config.use_semantic = False)
+        mc = ModelConfig(config=Config(use_semantic=False))
+    elif name == "P_NSL":  # semantic logits = bottleneck[1:1+K] (Config.no_sem_layer = True, models.py:1133), + intensity
+        mc = ModelConfig(config=Config(no_sem_layer=True, use_intensity=True))
+    elif name == "P_NSL0":  # the same without the intensity head
+        mc = ModelConfig(config=Config(no_sem_layer=True))
+    elif name == "P_W128I":  # width 128 with both heads
+        mc = ModelConfig(num_prop_samples=(), num_nerf_samples=64, num_levels=1, config=Config(use_intensity=True),
+                         nerf_mlp=MLPConfig(net_depth_viewdirs=4, net_width_viewdirs=128))
+    elif name == "P_D3":  # odd view depths: 3 x 256 ...
+        mc = ModelConfig(nerf_mlp=MLPConfig(net_depth_viewdirs=3, net_width_viewdirs=256))
+    elif name == "P_D5":  # ... and 5 x 128
+        mc = ModelConfig(num_prop_samples=(), num_nerf_samples=64, num_levels=1,
+                         nerf_mlp=MLPConfig(net_depth_viewdirs=5, net_width_viewdirs=128))
     else:
         raise ValueError(f"unknown workload {name!r}")
     if log2_hashmap is not None:

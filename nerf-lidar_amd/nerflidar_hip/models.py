@@ -207,6 +207,11 @@ class Model:
             h: Dict[str, torch.Tensor] = {"depth": new(n)}
             if want_history:
                 h.update(sdist=new(n, S + 1), tdist=new(n, S + 1), weights=new(n, S), density=new(n, S))
+                if li < len(samples) - 1:  # the rest of a proposal level's rendering dict (ZI/models.py:514-531)
+                    h.update(r_rgb=new(n, 3), r_acc=new(n))
+                    if compute_extras:
+                        for k in ("distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
+                            h["r_" + k] = new(n)
                 if li == len(samples) - 1:  # the library writes per-sample heads channel-/class-major
                     h["rgb"] = new(3, n, S)
                     if K:
@@ -249,9 +254,8 @@ class Model:
 
         `rand`: falsy for deterministic rendering; otherwise a torch.Generator (or True) used to draw the
         per-ray jitter (stepfun.py:216) and per-multisample rotation (render.py:150) on the device.
-        Proposal-level `renderings` carry only what consumers read from them (`depth`, ray_* bundles);
-        the full set of keys is produced for the last level (render consumers read `renderings[-1]`,
-        models.py:1460).
+        Every level's `renderings` entry carries the reference's keys (rgb, depth, acc, distance_* with compute_extras,
+        ray_* bundles; semantic / intensity on the last level only, models.py:514-531).
         """
         n = batch["origins"].shape[0]
         samples = self.mc.level_samples()
@@ -265,7 +269,7 @@ class Model:
         renderings = []
         for li, h in enumerate(hist):
             last = li == len(hist) - 1
-            rend = dict(r) if last else {"depth": h["depth"]}
+            rend = dict(r) if last else dict(depth=h["depth"], **{k[2:]: v for k, v in h.items() if k.startswith("r_")})
             if compute_extras:
                 nv = self.config.vis_num_rays
                 rend["ray_sdist"] = h["sdist"][:nv]
@@ -277,7 +281,7 @@ class Model:
             for li in range(len(hist) - 1):
                 S = samples[li]
                 renderings[li]["ray_rgbs"] = torch.broadcast_to(final_rgb[:, None, :], (final_rgb.shape[0], S, 3))
-        ray_history = [{k: v for k, v in h.items() if k != "depth"} for h in hist]
+        ray_history = [{k: v for k, v in h.items() if k != "depth" and not k.startswith("r_")} for h in hist]
         return renderings, ray_history
 
     __call__ = forward

@@ -58,7 +58,7 @@ def mlp_param_shapes(cfg: MLPConfig) -> List[Tuple[str, Tuple[int, int], bool]]:
         if i == cfg.skip_layer_dir:
             last += in_rgb
     out.append(("rgb_layer", (cfg.num_rgb_channels, last), False))
-    if cfg.use_semantic and not cfg.no_sem_layer and not cfg.fixed_semantic:  # models.py:954-957
+    if not cfg.no_sem_layer and not cfg.fixed_semantic:  # models.py:954-957 (built whether or not use_semantic reads it)
         out += [("sem_layer.0", (64, cfg.bottleneck_width), False), ("sem_layer.2", (cfg.class_num, 64), False)]
     if cfg.use_intensity:  # models.py:958-961
         out += [("intensity_layer.0", (64, cfg.bottleneck_width), False), ("intensity_layer.2", (1, 64), False)]

@@ -260,7 +260,17 @@ def gen_mlp_and_forward():
         ("C2_small", "C2", 15, 64, 16, 0, True),
         ("REF_full", "REF", None, 64, 16, 1, True),
         ("REF_init", "REF", 15, 64, 16, 0, False),
+        # the parameter space of ZI/models.py:MLP beyond the named configurations (nerflidar_hip/config.py:workload)
+        ("P_NOSEM", "P_NOSEM", 15, 64, 16, 2, True),
+        ("P_NSL", "P_NSL", 15, 64, 16, 3, True),
+        ("P_NSL0", "P_NSL0", 15, 64, 16, 4, True),
+        ("P_W128I", "P_W128I", 15, 64, 16, 5, True),
+        ("P_D3", "P_D3", 15, 64, 16, 6, True),
+        ("P_D5", "P_D5", 15, 64, 16, 7, True),
     ]
+    only = os.environ.get("NLR_GOLDEN_ONLY")  # regenerate a subset: comma-separated case names
+    if only:
+        cases = [c for c in cases if c[0] in only.split(",")]
     for name, wl, lg, N, width, seed, tl in cases:
         print(f"whole-forward fixture {name}")
         mc = nconfig.workload(wl, lg)
@@ -281,6 +291,9 @@ def gen_mlp_and_forward():
                 if h.get(k) is not None and not (k == "rgb" and lvl < len(hist) - 1):
                     out[f"hist{lvl}_{k}"] = h[k][:K]
             out[f"lvl{lvl}_depth"] = rend[lvl]["depth"]
+            if name.startswith("P_") and lvl < len(hist) - 1:  # the whole rendering dict of the proposal levels
+                for k in ("rgb", "acc", "distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
+                    out[f"lvl{lvl}_{k}"] = rend[lvl][k]
         save(f"fwd_{name}", workload=np.array(wl), log2_hashmap=np.array(-1 if lg is None else lg),
              seed=np.array(seed), trained_like=np.array(int(tl)), width=np.array(width),
              beams=np.array(beams), **{"in_" + k: v for k, v in batch_np.items()
@@ -470,6 +483,9 @@ def gen_objects():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if os.environ.get("NLR_GOLDEN_ONLY"):  # only some whole-forward fixtures
+        gen_mlp_and_forward()
+        raise SystemExit(0)
     gen_stepfun()
     gen_coord_render()
     gen_lidar()

@@ -29,8 +29,8 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.NlrLinear) == 24
     assert C.sizeof(_lib.NlrGridDesc) == 56
     assert C.sizeof(_lib.NlrRays) == 64
-    assert C.sizeof(_lib.NlrLevelOut) == 64
-    assert C.sizeof(_lib.NlrOut) == 12 * 8 + 8 + 4 * 64
+    assert C.sizeof(_lib.NlrLevelOut) == 112
+    assert C.sizeof(_lib.NlrOut) == 12 * 8 + 8 + 4 * 112
     assert C.sizeof(_lib.NlrRenderCfg) == 16 + 2 * 32 + 8
 
 
