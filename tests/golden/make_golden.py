@@ -112,6 +112,7 @@ sys.path.insert(0, REF)
 os.chdir("/tmp")
 from internal import math as rmath, stepfun as rstep, render as rrender, coord as rcoord, models as rmodels  # noqa: E402
 from internal import lidar_utils as rlidar  # noqa: E402
+from internal import checkpoints as rcheckpoints  # noqa: E402
 
 
 # ---------------------------------------------------------------------------- helpers
@@ -480,9 +481,86 @@ def gen_objects():
          imap=imap, **out)
 
 
+def gen_raydrop_apply():
+    """f-4: the reference's ray-drop application itself, NeRF_Lidar_code/src/drop_simulation_rays.py:drop_simulation, run end to
+    end (Generate_feature.generate_simulation_data -> LaserScan projection -> runner.test -> mask rule -> sky / road-outlier
+    drop) on a synthetic simulated sweep, with the UNet replaced by a runner that returns seeded logits.  Both branches of the
+    mask rule (plain threshold; place_car = cars thresholded at their median) in the `save_near` form our apply_ray_drop covers."""
+    print("ray-drop application fixture (reference drop_simulation_rays.drop_simulation)")
+    import tempfile
+    src = "/root/reference/NeRF_LiDAR/NeRF_Lidar_code/src"
+    sys.path.insert(0, src)
+    for n in ("tkinter", "imageio", "open3d", "matplotlib", "matplotlib.pyplot", "mayavi", "mayavi.mlab"):
+        if n not in sys.modules:
+            _stub(n)
+    _stub("tkinter.tix", Tree=object)
+    _stub("model")
+    _stub("model.ray_drop_train", ray_drop_learning=object)
+    for _ in range(8):
+        try:
+            import drop_simulation_rays as dsr
+            break
+        except ModuleNotFoundError as e:  # plotting / IO packages the script imports and this path never calls
+            _stub(e.name)
+    H, W = 32, 1024
+    d = nlidar.get_directions(nlidar.LIDAR_ANGLES, np.linspace(270, -90, 256) / 180 * np.pi).astype(np.float64)
+    rr = synth.uniform(5, 60, (d.shape[0],), 1.0, 60.0).astype(np.float64)
+    pts = d * rr[:, None] + synth.uniform(5, 61, d.shape, -0.01, 0.01)
+    pts = np.concatenate([pts, pts[:700] * 1.3], 0)
+    sem = np.floor(synth.uniform(5, 62, (pts.shape[0],), 0, 19)).astype(np.float32)
+    sem[::7] = 13.0   # cars
+    sem[3::11] = 10.0  # sky
+    sem[5::13] = 0.0   # road; some of them far below the sensor
+    pts[5::13, 2] -= 4.0
+    logits = synth.uniform(5, 63, (2, H, W), -2.0, 2.0).astype(np.float32)
+
+    class Runner:
+        def test(self, feats):
+            return logits.copy(), np.zeros((1, 1, H, W), np.float32)
+
+    out = dict(points=pts, semantic=sem)  # (the logits are synth.uniform(5, 63, (2, 32, 1024), -2, 2): regenerated by the tests)
+    with tempfile.TemporaryDirectory() as tmp:
+        sim, data = os.path.join(tmp, "sim"), os.path.join(tmp, "data")
+        os.makedirs(sim); os.makedirs(data)
+        np.save(os.path.join(sim, "points_0000.npy"), pts)
+        np.save(os.path.join(sim, "points_semantic_0000.npy"), sem)
+        np.save(os.path.join(data, "c2w.npy"), np.eye(4))
+        np.save(os.path.join(data, "c2w_recenter_transform.npy"), np.eye(4))
+        for tag, place_car in (("plain", False), ("car", True)):
+            dsr.args = types.SimpleNamespace(verbose=False, depth_filter=0, semantic_align=False, filter_thre=0.0, dist_thre=0.0,
+                                             place_car=place_car, mask_thre=0.5, pre_mask=False, var=True, normalize=False,
+                                             onehot_encoding=False)
+            rp, rl = dsr.drop_simulation(sim, tmp, [np.eye(4)], Runner(), {}, {}, save_near=True, datadir=data, mask_thre=0.5)
+            out[f"{tag}_points"], out[f"{tag}_labels"] = rp[0], rl[0]
+            print(f"  {tag}: {len(rl[0])} of {len(sem)} points remain")
+    save("fn_raydrop_apply", **out)
+
+
+def gen_checkpoint():
+    """f-4: a checkpoint written by the reference's own internal/checkpoints.py:save_checkpoint from the reference Model's
+    state_dict (the file train.py:559-566 leaves on disk), for the importer to read.  Small architecture (4 x 128, 2^9-entry tables)."""
+    print("checkpoint fixture (reference internal/checkpoints.save_checkpoint)")
+    import tempfile
+    import shutil
+    mc = nconfig.workload("C1", 9)
+    sd_np = nweights.synth_state_dict(mc, seed=21, trained_like=True)
+    model = build_ref_model(mc, sd_np)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = rcheckpoints.save_checkpoint(tmp, {"state_dict": model.state_dict(), "optimizer": opt.state_dict()}, 1234)
+        dst = os.path.join(HERE, "ckpt_ref")
+        os.makedirs(dst, exist_ok=True)
+        shutil.copy(path, os.path.join(dst, os.path.basename(path)))
+        print(f"  wrote ckpt_ref/{os.path.basename(path)}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if os.environ.get("NLR_GOLDEN_ONLY") == "f4":
+        gen_raydrop_apply()
+        gen_checkpoint()
+        raise SystemExit(0)
     if os.environ.get("NLR_GOLDEN_ONLY"):  # only some whole-forward fixtures
         gen_mlp_and_forward()
         raise SystemExit(0)
@@ -495,4 +573,6 @@ if __name__ == "__main__":
     gen_range_image()
     gen_objects()
     gen_composite_grad()
+    gen_raydrop_apply()
+    gen_checkpoint()
     print("done")

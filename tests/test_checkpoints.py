@@ -128,7 +128,44 @@ def test_write_points_and_labels_kitti_layout(tmp_path):
     np.testing.assert_array_equal(l, lab.astype(np.uint32))
 
 
+def test_reads_a_checkpoint_written_by_the_reference():
+    """tests/golden/ckpt_ref/checkpoint_1234.ckpt was written by the REFERENCE's internal/checkpoints.py:save_checkpoint from the
+    reference Model's state_dict (tests/golden/make_golden.py:gen_checkpoint): the importer must read that file, recover the
+    architecture from the tensor shapes and hand back exactly the parameters the reference model held."""
+    from conftest import GOLDEN
+    d = os.path.join(GOLDEN, "ckpt_ref")
+    assert os.path.basename(ck.latest_checkpoint(d)) == "checkpoint_1234.ckpt"
+    sd, step = ck.load_checkpoint(d)
+    assert step == 1234
+    mc = nconfig.workload("C1", 9)
+    want = nweights.synth_state_dict(mc, seed=21, trained_like=True)
+    keep, ignored = ck.split_state_dict(sd)
+    assert ignored == []
+    for k, v in want.items():  # (split_state_dict sets the encoder buffers aside: they are re-derived from the configuration)
+        np.testing.assert_array_equal(sd[k], v, err_msg=k)
+        assert k in keep or k.rsplit(".", 1)[-1] in ("offsets", "grid_sizes", "idx"), k
+    assert "nerf_mlp.encoder.idx" in sd  # the buffer the reference registers and we re-derive
+    got = ck.infer_model_config(keep, nconfig.ModelConfig(num_prop_samples=(), num_nerf_samples=64, num_levels=1))
+    assert got.nerf_mlp.net_depth_viewdirs == 4 and got.nerf_mlp.net_width_viewdirs == 128
+    assert got.nerf_mlp.grid_log2_hashmap_size == 9 and got.config.use_semantic and not got.config.use_intensity
+
+
 # ---- GPU ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_reference_written_checkpoint_renders_like_its_parameters():
+    from conftest import GOLDEN
+    from nerflidar_hip import lidar as nlidar
+    from nerflidar_hip.models import Model
+    mc = nconfig.workload("C1", 9)
+    base = nconfig.ModelConfig(num_prop_samples=(), num_nerf_samples=64, num_levels=1)
+    m2, step, ignored = ck.model_from_checkpoint(os.path.join(GOLDEN, "ckpt_ref"), base=base)
+    m1 = Model(mc, nweights.synth_state_dict(mc, seed=21, trained_like=True))
+    b = nlidar.synthetic_sweep(width=16, seed=2)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    r1, r2 = m1.render_rays(batch)[0], m2.render_rays(batch)[0]
+    for k in ("depth", "rgb", "semantic"):
+        assert torch.equal(r1[k], r2[k]), k
+
 @pytest.mark.gpu
 def test_model_from_checkpoint_renders_identically(tmp_path):
     from nerflidar_hip import lidar as nlidar

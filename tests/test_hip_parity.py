@@ -277,8 +277,21 @@ def test_mlp_level(name, precision):
     # fine levels (resolution 8192): a 1-ulp difference of a contracted coordinate (libm sqrt/pow, FMA use in
     # the basis product) moves the cell fraction by 8191 * 6e-8 = 5e-4, i.e. features by up to ~1e-4
     np.testing.assert_allclose(npy(feat), ref_feat, atol=2e-4, rtol=1e-4)
-    # density: pre-activation is the feature error times the x1500 "trained-like" gain of density_layer.2 row 0
+    # density against the reference: the pre-activation carries the feature error above times the x1500 "trained-like" gain of
+    # density_layer.2 row 0, hence the loose gate here ...
     np.testing.assert_allclose(npy(dens), g["density"], atol=5e-2, rtol=2e-3)
+    # ... and the tight one on the MLP arithmetic itself: the trunk in float64 on the features the GPU produced, tolerance relative
+    # to the gain sum_j |W2[0,j] h_j| of the raw density (split-bf16: ~2^-16 per product; exact-f32 MFMA: f32 rounding)
+    f64 = npy(feat).astype(np.float64)
+    W1, b1 = sd["nerf_mlp.density_layer.0.weight"].astype(np.float64), sd["nerf_mlp.density_layer.0.bias"].astype(np.float64)
+    W2, b2 = sd["nerf_mlp.density_layer.2.weight"].astype(np.float64), sd["nerf_mlp.density_layer.2.bias"].astype(np.float64)
+    hid = np.maximum(f64 @ W1.T + b1, 0.0)
+    raw = hid @ W2[0] + b2[0] + mc.nerf_mlp.density_bias
+    gain = np.abs(hid) @ np.abs(W2[0]) + np.abs(f64) @ np.abs(W1.T) @ np.abs(W2[0]) + 1.0
+    ref_d = np.where(raw > 20, raw, np.log1p(np.exp(np.minimum(raw, 20))))
+    rel = 3e-5 if precision == _lib.PREC_FAST else 2e-6
+    err = np.abs(npy(dens).reshape(-1).astype(np.float64) - ref_d)
+    assert (err <= rel * gain + 1e-6).all(), f"density vs f64 trunk on the GPU's features: max err/gain {np.max(err / gain):.3e} (allowed {rel})"
     np.testing.assert_allclose(npy(sem.permute(1, 2, 0)), g["semantic"], atol=2e-3, rtol=1e-3)
     if inten is not None:
         np.testing.assert_allclose(npy(inten), g["intensity"][..., 0], atol=1e-3, rtol=1e-3)

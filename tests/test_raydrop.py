@@ -60,6 +60,39 @@ def test_range_projection_oracle_matches_reference():
     assert (g["proj_idx"] >= 0).sum() > 3000 and (g["proj_mask"] == 0).sum() > 0
 
 
+def _apply_fixture():
+    from nerflidar_hip import synth
+    g = golden("fn_raydrop_apply")
+    logits = synth.uniform(5, 63, (2, 32, 1024), -2.0, 2.0).astype(np.float32)  # what the fixture's stub runner returned
+    return g, logits
+
+
+@pytest.mark.parametrize("tag,place_car", [("plain", False), ("car", True)])
+def test_apply_ray_drop_matches_reference_run(tag, place_car):
+    """f-4: `apply_ray_drop` against the REFERENCE's drop_simulation_rays.drop_simulation run end to end on the same sweep and
+    logits (tests/golden/make_golden.py:gen_raydrop_apply): same surviving points, same labels, same order.  The projection
+    here is the oracle's (CPU); the GPU test below runs the HIP projection."""
+    from oracle import nlr_oracle as orc
+    g, logits = _apply_fixture()
+    o = orc.range_projection(g["points"], g["semantic"], None, H=32, W=1024)
+    proj = {k: torch.from_numpy(np.asarray(v)) for k, v in o.items() if v is not None}
+    pts, lab = raydrop.apply_ray_drop(proj, torch.from_numpy(logits), mask_thre=0.5, place_car=place_car)
+    np.testing.assert_array_equal(lab.numpy(), g[f"{tag}_labels"].astype(np.int64))
+    np.testing.assert_array_equal(pts.numpy().astype(np.float32), g[f"{tag}_points"].astype(np.float32))
+    assert 2000 < len(lab) < len(g["semantic"]) and (lab != 10).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,place_car", [("plain", False), ("car", True)])
+def test_apply_ray_drop_on_gpu_matches_reference_run(tag, place_car):
+    g, logits = _apply_fixture()
+    dev = "cuda:0"
+    proj = raydrop.range_projection(torch.from_numpy(g["points"]).to(dev), torch.from_numpy(g["semantic"]).to(dev), None, H=32, W=1024)
+    pts, lab = raydrop.apply_ray_drop(proj, torch.from_numpy(logits).to(dev), mask_thre=0.5, place_car=place_car)
+    np.testing.assert_array_equal(lab.cpu().numpy(), g[f"{tag}_labels"].astype(np.int64))
+    np.testing.assert_array_equal(pts.cpu().numpy().astype(np.float32), g[f"{tag}_points"].astype(np.float32))
+
+
 @pytest.mark.gpu
 def test_range_projection_gpu_bit_exact():
     """nlr_range_project (HIP) against the reference's projection: every pixel picks the same (nearest) point."""
@@ -80,6 +113,24 @@ def test_range_projection_gpu_bit_exact():
     # empty input and the mask quirk
     e = raydrop.range_projection(torch.zeros(0, 3, dtype=torch.float64, device=dev), H=4, W=8)
     assert (e["proj_idx"] == -1).all() and (e["proj_range"] == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,reg", [("logits", False), ("regression", True)])
+def test_unet_matches_reference_on_gpu(tag, reg):
+    """The same fixtures as test_unet_matches_reference (outputs of the reference's UNet), through MIOpen on the GPU."""
+    g = golden(f"unet_{tag}")
+    m = raydrop.UNet(n_channels=6, n_classes=2, bilinear=True, regression=reg).eval()
+    unet_fill(m, 7)
+    m = m.to("cuda:0")
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["x"]).to("cuda:0"))
+    logits = out[0] if reg else out
+    # MIOpen convolutions sum in another order than the CPU reference: 1e-4 absolute on logits of magnitude ~1
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], atol=1e-4, rtol=1e-4)
+    if reg:
+        np.testing.assert_allclose(out[1].cpu().numpy(), g["reg"], atol=1e-4, rtol=1e-4)
+    assert (logits.argmax(1).cpu().numpy() == g["logits"].argmax(1)).mean() > 0.999  # the keep/drop decision itself
 
 
 @pytest.mark.gpu
