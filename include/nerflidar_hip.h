@@ -286,6 +286,35 @@ int nlr_hash_decay_backward(const float *embeddings, const int32_t *offsets_host
                             float *grad_embeddings, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * (6b) Fused NerfMLP for training: forward that also saves every layer's output, and the backward of what
+ *     autograd does for the reference's Linear stack in `loss.backward()` (Z/train.py:272-281,459; ZI/models.py:1116-1251:
+ *     density_layer, sem_layer, intensity_layer, lin_second_stage_* with the skip concat, rgb_layer; ReLU, softplus, softmax,
+ *     sigmoid), both as one MFMA chain per 32 samples (bf16 operands, f32 accumulation: mixed-precision training).
+ *     A plan fixes the shapes and the order of the flat parameter buffer: for each Linear in the order density_layer.0,
+ *     density_layer.2, [sem_layer.0, sem_layer.2], [intensity_layer.0, intensity_layer.2], lin_second_stage_0..D-1, rgb_layer its
+ *     weight (row-major [out, in]) then its bias; nlr_train_param_layout returns the offsets (2 per Linear).  nlr_train_pack
+ *     re-packs the weight tapes on the device from that buffer (call it after every optimizer step).
+ *     forward: features [M, F] f32 row-major, enc [M / S, 32] (pos_enc of the ray's viewdirs, zero padded); outputs in the
+ *       layouts of nlr_mlp_level; acts [M, nlr_train_act_width()] bf16 = [hid 64 | bottleneck | head hidden | x_0 .. x_{D-1}].
+ *     backward: upstream gradients in the layouts of the outputs (NULL = zero); gacts [M, act_width + 64] bf16 = the gradient of
+ *       every pre-activation in the columns of acts, then [d head outputs 32 | d rgb_layer outputs 32]; d_features [M, F] f32.
+ *       The weight gradients are GEMMs over these tensors, dW_l = gacts_l^T . acts_{l-1} (plain library GEMMs, host side).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct NlrTrainPlan NlrTrainPlan;
+int nlr_train_plan_create(uint32_t F, uint32_t W, uint32_t WB, uint32_t D, uint32_t deg_view, uint32_t class_num,
+                          int use_semantic, int use_intensity, float density_bias, float rgb_premultiplier, float rgb_bias,
+                          float rgb_padding, NlrTrainPlan **out, uint32_t *n_params);
+void nlr_train_plan_destroy(NlrTrainPlan *p);
+uint32_t nlr_train_act_width(const NlrTrainPlan *p);
+int nlr_train_param_layout(const NlrTrainPlan *p, uint32_t *offsets, uint32_t capacity);
+int nlr_train_pack(NlrTrainPlan *p, const float *params_dev, void *stream);
+int nlr_mlp_train_forward(const NlrTrainPlan *p, const float *features, const float *enc, uint32_t M, uint32_t S, float *density,
+                          float *rgb, float *semantic, float *intensity, void *acts, void *stream);
+int nlr_mlp_train_backward(const NlrTrainPlan *p, uint32_t M, uint32_t S, const float *density, const float *rgb,
+                           const float *semantic, const void *acts, const float *g_density, const float *g_rgb,
+                           const float *g_semantic, const float *g_intensity, void *gacts, float *d_features, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * (7) Dynamic-object branch: owner of every sample.  winner [N,S] int32 = index of the LAST
  *     track whose box contains the sample's interval midpoint (ZI/models.py:415,475 let later tracks overwrite
  *     earlier ones; ZI/obj_utils.py:203-216 inside test), -1 outside every box.  box_params [N, n_obj, 8] =

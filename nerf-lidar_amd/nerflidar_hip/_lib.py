@@ -73,7 +73,9 @@ EXPORTS = ["nlr_last_error", "nlr_version", "nlr_grid_encode_forward", "nlr_grid
            "nlr_sample_u", "nlr_model_create", "nlr_model_destroy", "nlr_model_set_table", "nlr_workspace_bytes",
            "nlr_render_rays", "nlr_kernel_names", "nlr_resample_level", "nlr_mlp_level", "nlr_composite_level",
            "nlr_profile_begin", "nlr_profile_end", "nlr_range_workspace_bytes", "nlr_range_project",
-           "nlr_composite_backward", "nlr_hash_decay_forward", "nlr_hash_decay_backward", "nlr_box_winner", "nlr_cast_contract"]
+           "nlr_composite_backward", "nlr_hash_decay_forward", "nlr_hash_decay_backward", "nlr_box_winner", "nlr_cast_contract",
+           "nlr_train_plan_create", "nlr_train_plan_destroy", "nlr_train_act_width", "nlr_train_param_layout", "nlr_train_pack",
+           "nlr_mlp_train_forward", "nlr_mlp_train_backward"]
 NLR_K_COUNT = 6
 
 
@@ -123,6 +125,15 @@ def lib():
         L.nlr_cast_contract.argtypes = [C.POINTER(NlrRays), c_fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, c_fp, c_fp, c_fp,
                                         c_fp]
         L.nlr_box_winner.argtypes = [c_fp, c_fp, c_fp, c_fp, C.c_uint32, C.c_uint32, C.c_uint32, c_fp, c_fp]
+        L.nlr_train_plan_create.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int] + [C.c_float] * 4 + [C.POINTER(c_fp), C.POINTER(C.c_uint32)]
+        L.nlr_train_plan_destroy.restype = None
+        L.nlr_train_plan_destroy.argtypes = [c_fp]
+        L.nlr_train_act_width.restype = C.c_uint32
+        L.nlr_train_act_width.argtypes = [c_fp]
+        L.nlr_train_param_layout.argtypes = [c_fp, c_fp, C.c_uint32]
+        L.nlr_train_pack.argtypes = [c_fp, c_fp, c_fp]
+        L.nlr_mlp_train_forward.argtypes = [c_fp, c_fp, c_fp, C.c_uint32, C.c_uint32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
+        L.nlr_mlp_train_backward.argtypes = [c_fp, C.c_uint32, C.c_uint32] + [c_fp] * 11
         L.nlr_profile_begin.argtypes = [c_fp]
         L.nlr_profile_end.argtypes = [c_fp, c_fp, c_fp, c_fp]
         _lib = L

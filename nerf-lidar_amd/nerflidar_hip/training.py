@@ -165,6 +165,121 @@ def encode_features(encoder, means: torch.Tensor, stds: torch.Tensor, re_weights
     return f.flatten(-2, -1)
 
 
+# ---- fused NerfMLP for training: nlr_mlp_train_forward / nlr_mlp_train_backward (csrc/nlr_mlp_train.hip) ---------------------------
+class _FusedMLP(torch.autograd.Function):
+    """The Linear stack of ZI/models.py:1116-1251 (density trunk, heads, view MLP, rgb) as two MFMA-chain kernels.  The weight
+    gradients are GEMMs over the tensors those kernels save: dW_l = (d pre-activation_l)^T . (input_l), M-long reductions."""
+
+    @staticmethod
+    def forward(ctx, feats, enc, level, *params):
+        plan = level._plan
+        M, S = feats.shape[0], level._S
+        dev = feats.device
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        new = lambda *s, dtype=torch.float32: torch.empty(*s, device=dev, dtype=dtype)
+        K = level.cfg.class_num if level.cfg.use_semantic else 0
+        density, rgb = new(M), new(3, M)
+        sem = new(K, M) if K else None
+        inten = new(M) if level.cfg.use_intensity else None
+        acts = new(M, plan.act_w, dtype=torch.bfloat16)
+        f = feats.detach().contiguous().float()
+        e = enc.detach().contiguous().float()
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            st = _lib.current_stream()
+            _lib.check(L.nlr_train_pack(plan.handle, _lib.ptr(flat), st), "nlr_train_pack")
+            _lib.check(L.nlr_mlp_train_forward(plan.handle, _lib.ptr(f), _lib.ptr(e), M, S, _lib.ptr(density), _lib.ptr(rgb), _lib.ptr(sem),
+                                               _lib.ptr(inten), _lib.ptr(acts), st), "nlr_mlp_train_forward")
+        ctx.level, ctx.M = level, M
+        ctx.save_for_backward(f, e, density, rgb, sem if sem is not None else density.new_empty(0),
+                              inten if inten is not None else density.new_empty(0), acts)
+        outs = [density, rgb]
+        outs.append(sem if sem is not None else density.new_empty(0))
+        outs.append(inten if inten is not None else density.new_empty(0))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_density, g_rgb, g_sem, g_inten):
+        level, M = ctx.level, ctx.M
+        plan, cfg = level._plan, level.cfg
+        f, e, density, rgb, sem, inten, acts = ctx.saved_tensors
+        dev = f.device
+        K = cfg.class_num if cfg.use_semantic else 0
+        gp = lambda g, ref: None if (g is None or ref.numel() == 0) else g.contiguous().float()
+        gd, gr, gs, gi = gp(g_density, density), gp(g_rgb, rgb), gp(g_sem, sem), gp(g_inten, inten)
+        gacts = torch.empty(M, plan.act_w + 64, device=dev, dtype=torch.bfloat16)
+        d_feat = torch.empty_like(f)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nlr_mlp_train_backward(plan.handle, M, level._S, _lib.ptr(density), _lib.ptr(rgb),
+                                                         _lib.ptr(sem) if sem.numel() else None, _lib.ptr(acts), _lib.ptr(gd), _lib.ptr(gr),
+                                                         _lib.ptr(gs), _lib.ptr(gi), _lib.ptr(gacts), _lib.ptr(d_feat), _lib.current_stream()),
+                       "nlr_mlp_train_backward")
+        if getattr(level, "_keep_debug", False):  # tests look at the kernels' raw results
+            level._dbg = {k: v.detach() for k, v in dict(acts=acts, gacts=gacts, d_feat=d_feat, feats=f, enc=e, density=density, rgb=rgb,
+                                                        sem=sem, inten=inten).items()}
+        # ---- weight gradients: plain GEMMs over the saved tensors (f32 accumulate and result)
+        W, WB, D = cfg.net_width_viewdirs, cfg.bottleneck_width, cfg.net_depth_viewdirs
+        HH = (64 if K else 0) + (64 if cfg.use_intensity else 0)
+        c_hid, c_hbe, c_q, c_x = 0, 64, 64 + WB, 64 + WB + HH
+        a = lambda c0, n: acts[:, c0:c0 + n]
+        g = lambda c0, n: gacts[:, c0:c0 + n]
+        E = cfg.dim_dir_enc
+        enc_s = e[:, :E].to(torch.bfloat16).repeat_interleave(level._S, dim=0)  # the bf16 values the forward chain consumed
+
+        # [M, out]^T . [M, in_0 | in_1 | ..]: bf16 operands, f32 accumulation.  The reduction runs over M (10^5..10^6) into a
+        # 256 x 256 result: as ONE library GEMM that is 16 output tiles = 16 busy CUs, so M is cut into `ck` batches (split-K as a
+        # batched GEMM over strided views, no copies) whose partial results are summed in f32.
+        ck = 1
+        while ck < 128 and M % (2 * ck) == 0 and M // (2 * ck) >= 2048:
+            ck *= 2
+
+        def wgrad(gy, *xs):
+            gb = gy.reshape(ck, M // ck, gy.shape[1]).transpose(1, 2)
+            return torch.cat([torch.bmm(gb, x.reshape(ck, M // ck, x.shape[1])).float().sum(0) for x in xs], 1)
+
+        grads = []
+
+        def lin(gy, *xs):
+            grads.append(wgrad(gy, *xs))
+            grads.append(torch.sum(gy, 0, dtype=torch.float32))
+
+        lin(g(c_hid, 64), f.to(torch.bfloat16))
+        lin(g(c_hbe, WB), a(c_hid, 64))
+        r0 = 0
+        if K:
+            lin(g(c_q, 64), a(c_hbe, WB))
+            lin(g(plan.act_w, K), a(c_q, 64))
+            r0 = 64
+        if cfg.use_intensity:
+            lin(g(c_q + r0, 64), a(c_hbe, WB))
+            lin(g(plan.act_w + K, 1), a(c_q + r0, 64))
+        lin(g(c_x, W), a(c_hbe, WB), enc_s)
+        if D > 1:
+            lin(g(c_x + W, W), a(c_x, W), a(c_hbe, WB), enc_s)
+        for l in range(2, D):
+            lin(g(c_x + l * W, W), a(c_x + (l - 1) * W, W))
+        lin(g(plan.act_w + 32, 3), a(c_x + (D - 1) * W, W))
+        return (d_feat, None, None) + tuple(grads)
+
+
+class _TrainPlan:
+    def __init__(self, cfg):
+        h, n = C.c_void_p(None), C.c_uint32(0)
+        F = cfg.grid_num_levels * cfg.grid_level_dim
+        _lib.check(_lib.lib().nlr_train_plan_create(F, cfg.net_width_viewdirs, cfg.bottleneck_width, cfg.net_depth_viewdirs, cfg.deg_view,
+                                                    cfg.class_num, int(cfg.use_semantic and not cfg.no_sem_layer), int(cfg.use_intensity),
+                                                    cfg.density_bias, cfg.rgb_premultiplier, cfg.rgb_bias, cfg.rgb_padding,
+                                                    C.byref(h), C.byref(n)), "nlr_train_plan_create")
+        self.handle, self.n_params = h, int(n.value)
+        self.act_w = int(_lib.lib().nlr_train_act_width(h))
+
+    def __del__(self):
+        try:
+            _lib.lib().nlr_train_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class TrainableNerfLevel(torch.nn.Module):
     """The final (NerfMLP) level as a trainable module with the reference's parameter names (`encoder.embeddings`,
     `density_layer.0.weight`, `lin_second_stage_3.bias`, `sem_layer.2.weight`, ...; ZI/models.py:847-961), so that
@@ -172,11 +287,17 @@ class TrainableNerfLevel(torch.nn.Module):
     `nerflidar_hip.models.Model` for fused inference.  forward = MLP.forward (models.py:1036-1265, inference subset:
     disable_density_normals, no GLO) on the intervals of `tdist`; `render` adds the compositing."""
 
-    def __init__(self, cfg, table_std: float = 1e-4):
+    def __init__(self, cfg, table_std: float = 1e-4, fused_mlp: bool = False):
+        """fused_mlp: run the Linear stack through nlr_mlp_train_forward / _backward (bf16 MFMA chains, f32 accumulation) instead
+        of torch Linear modules; parameters, their names and their gradients are the same objects either way."""
         super().__init__()
         from .gridencoder import GridEncoder
         nn = torch.nn
         self.cfg = cfg
+        self.fused_mlp = bool(fused_mlp)
+        self._plan = None
+        if self.fused_mlp and cfg.use_semantic and cfg.no_sem_layer:
+            raise NotImplementedError("fused training MLP: no_sem_layer=True is not wired (use fused_mlp=False)")
         self.encoder = GridEncoder(input_dim=3, num_levels=cfg.grid_num_levels, level_dim=cfg.grid_level_dim,
                                    base_resolution=cfg.grid_base_resolution, desired_resolution=cfg.grid_disired_resolution,
                                    log2_hashmap_size=cfg.grid_log2_hashmap_size, gridtype="hash", align_corners=False)
@@ -190,7 +311,7 @@ class TrainableNerfLevel(torch.nn.Module):
             self.add_module(f"lin_second_stage_{i}", lin)
             last = cfg.net_width_viewdirs + (in_rgb if i == cfg.skip_layer_dir else 0)
         self.rgb_layer = nn.Linear(last, cfg.num_rgb_channels)
-        if cfg.use_semantic and not cfg.no_sem_layer:
+        if not cfg.no_sem_layer and not cfg.fixed_semantic:  # built whether or not use_semantic reads it (ZI/models.py:954-957)
             self.sem_layer = nn.Sequential(nn.Linear(cfg.bottleneck_width, 64), nn.ReLU(), nn.Linear(64, cfg.class_num))
         if cfg.use_intensity:
             self.intensity_layer = nn.Sequential(nn.Linear(cfg.bottleneck_width, 64), nn.ReLU(), nn.Linear(64, 1))
@@ -209,6 +330,8 @@ class TrainableNerfLevel(torch.nn.Module):
         F = torch.nn.functional
         cfg = self.cfg
         means, stds = cast_contract(batch, tdist, sample_n, sample_m)
+        if self.fused_mlp:
+            return self._forward_fused(batch, encode_features(self.encoder, means, stds, cfg.re_weights))
         x = self.density_layer(encode_features(self.encoder, means, stds, cfg.re_weights))
         out = {"density": F.softplus(x[..., 0] + cfg.density_bias)}
         if cfg.use_semantic:
@@ -224,6 +347,39 @@ class TrainableNerfLevel(torch.nn.Module):
                 h = torch.cat([h, inputs], dim=-1)
         rgb = torch.sigmoid(cfg.rgb_premultiplier * self.rgb_layer(h) + cfg.rgb_bias)
         out["rgb"] = rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
+        return out
+
+    def _mlp_params(self):
+        """The Linear parameters in the order of the plan's flat buffer (include/nerflidar_hip.h, section 6b)."""
+        cfg = self.cfg
+        mods = [self.density_layer[0], self.density_layer[2]]
+        if cfg.use_semantic and not cfg.no_sem_layer:
+            mods += [self.sem_layer[0], self.sem_layer[2]]
+        if cfg.use_intensity:
+            mods += [self.intensity_layer[0], self.intensity_layer[2]]
+        mods += [getattr(self, f"lin_second_stage_{i}") for i in range(cfg.net_depth_viewdirs)] + [self.rgb_layer]
+        out = []
+        for m in mods:
+            out += [m.weight, m.bias]
+        return out
+
+    def _forward_fused(self, batch, feats):
+        from .objects import _pos_enc
+        cfg = self.cfg
+        n, S = feats.shape[0], feats.shape[1]
+        if self._plan is None:
+            self._plan = _TrainPlan(cfg)
+        self._S = S
+        params = self._mlp_params()
+        assert sum(p.numel() for p in params) == self._plan.n_params
+        enc = torch.zeros(n, 32, device=feats.device)
+        enc[:, :cfg.dim_dir_enc] = _pos_enc(batch["viewdirs"].reshape(n, 3).float(), cfg.deg_view)
+        density, rgb, sem, inten = _FusedMLP.apply(feats.reshape(n * S, -1), enc, self, *params)
+        out = {"density": density.reshape(n, S), "rgb": rgb.reshape(3, n, S).permute(1, 2, 0)}
+        if cfg.use_semantic:
+            out["semantic"] = sem.reshape(-1, n, S).permute(1, 2, 0)
+        if cfg.use_intensity:
+            out["intensity"] = inten.reshape(n, S)
         return out
 
     def render(self, batch, tdist, opaque_background: bool = True, bg: float = 1.0, **kw):

@@ -203,3 +203,160 @@ def test_trainable_level_matches_oracle_forward_and_gradients():
     cm, cs = cm.reshape(means.shape), cs.reshape(stds.shape)
     np.testing.assert_allclose(m_hip.cpu().numpy(), (cm / 2).numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(s_hip.cpu().numpy(), (cs / 2).numpy(), rtol=2e-5, atol=1e-9)
+
+
+def _bf16_ste(t):
+    """round to bf16 in value, identity in gradient: what a bf16 MFMA operand is to the f32 chain around it"""
+    return t + (t.to(torch.bfloat16).float() - t).detach()
+
+
+def _level_forward_bf16_operands(lvl, batch, tdist):
+    """TrainableNerfLevel.forward with every Linear's input and weight rounded to bf16 (f32 accumulation, f32 bias): the arithmetic
+    of the fused kernels, written with torch ops so that torch autograd provides the gradients to compare with."""
+    from nerflidar_hip import training
+    from nerflidar_hip.objects import _pos_enc
+    F = torch.nn.functional
+    cfg = lvl.cfg
+    lin = lambda m, x: F.linear(_bf16_ste(x), _bf16_ste(m.weight), m.bias)
+    means, stds = training.cast_contract(batch, tdist)
+    f = training.encode_features(lvl.encoder, means, stds, cfg.re_weights)
+    x = lin(lvl.density_layer[2], F.relu(lin(lvl.density_layer[0], f)))
+    out = {"density": F.softplus(x[..., 0] + cfg.density_bias)}
+    if cfg.use_semantic:
+        out["semantic"] = torch.softmax(lin(lvl.sem_layer[2], F.relu(lin(lvl.sem_layer[0], x))), -1)
+    if cfg.use_intensity:
+        out["intensity"] = lin(lvl.intensity_layer[2], F.relu(lin(lvl.intensity_layer[0], x)))[..., 0]
+    enc = _pos_enc(batch["viewdirs"].reshape(x.shape[0], 3).float(), cfg.deg_view)
+    h = torch.cat([x, enc[:, None, :].expand(-1, x.shape[1], -1)], dim=-1)
+    inputs = h
+    for i in range(cfg.net_depth_viewdirs):
+        h = F.relu(lin(getattr(lvl, f"lin_second_stage_{i}"), h))
+        if i == cfg.skip_layer_dir:
+            h = torch.cat([h, inputs], dim=-1)
+    rgb = torch.sigmoid(cfg.rgb_premultiplier * lin(lvl.rgb_layer, h) + cfg.rgb_bias)
+    out["rgb"] = rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wl,S", [("C2", 32), ("REF", 32), ("P_W128I", 64), ("P_NOSEM", 32), ("P_D3", 32)])
+def test_fused_training_mlp_matches_torch_autograd(wl, S):
+    """f-3: nlr_mlp_train_forward / nlr_mlp_train_backward (bf16 MFMA chains, f32 accumulation) against torch autograd through the
+    SAME level's Linear stack evaluated with bf16-rounded operands (the kernels' arithmetic; against an f32 forward a bf16
+    forward flips ~1 % of the ReLU masks, which alone is a 10 % gradient difference): outputs, the gradient of every Linear
+    weight and bias, and the gradient that reaches the hash table through the feature gradient.  What remains is the bf16
+    rounding of the activation gradients between the layers of the backward chain: 2e-2 of each tensor's norm."""
+    from nerflidar_hip import config as nconfig, lidar as nlidar, training, weights as nweights
+    mc = nconfig.workload(wl, 12)
+    sd = nweights.synth_state_dict(mc, seed=5, trained_like=False)
+    # a livelier random scene than the reference init, without the x1500 density gain of trained_like (bf16 operands)
+    for k in sd:
+        if k.endswith("encoder.embeddings"):
+            sd[k] = (sd[k] * 3e3).astype(np.float32)
+    b = nlidar.synthetic_sweep(width=6, seed=5, beams=nlidar.LIDAR_ANGLES[::8])
+    N = b["origins"].shape[0]
+    rng = np.random.default_rng(0)
+    tdist = torch.from_numpy(np.sort(rng.uniform(0.01, 1.5, (N, S + 1)).astype(np.float32), axis=-1)).cuda()
+    batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    cfg = mc.nerf_mlp
+    ref = training.TrainableNerfLevel(cfg).load_reference(sd).cuda()
+    fus = training.TrainableNerfLevel(cfg, fused_mlp=True).load_reference(sd).cuda()
+    cot = {"density": rng.normal(size=(N, S)), "rgb": rng.normal(size=(N, S, 3))}
+    if cfg.use_semantic:
+        cot["semantic"] = rng.normal(size=(N, S, cfg.class_num))
+    if cfg.use_intensity:
+        cot["intensity"] = rng.normal(size=(N, S))
+    cot = {k: torch.from_numpy(v.astype(np.float32)).cuda() for k, v in cot.items()}
+    fus._keep_debug = True
+    outs = {}
+    for name, lvl in (("ref", ref), ("fus", fus)):
+        o = _level_forward_bf16_operands(lvl, batch, tdist) if name == "ref" else lvl(batch, tdist)
+        sum((o[k] * cot[k]).sum() for k in cot).backward()
+        outs[name] = {k: v.detach().float().cpu().numpy() for k, v in o.items()}
+
+    def close(name, got, want, rel):
+        err = float(np.linalg.norm(got - want)) / max(float(np.linalg.norm(want)), 1e-30)
+        assert err <= rel, f"{wl} {name}: relative norm error {err:.3e} > {rel}"
+
+    # (1) forward: the kernels' arithmetic written in torch
+    for k in cot:
+        close(k, outs["fus"][k], outs["ref"][k], 2e-3)
+
+    # (2) backward kernel, layer by layer, against the chain rule in float64 ON THE ACTIVATIONS THE FORWARD KERNEL SAVED (same ReLU
+    # masks by construction) with bf16-rounded weights and the bf16 rounding of each gradient tile between layers that the kernel
+    # applies: what is left is f32 accumulation order and the rounding of the stored value itself
+    torch.set_grad_enabled(False)
+    d = fus._dbg
+    M = N * S
+    W, WB, D, K = cfg.net_width_viewdirs, cfg.bottleneck_width, cfg.net_depth_viewdirs, (cfg.class_num if cfg.use_semantic else 0)
+    HH = (64 if K else 0) + (64 if cfg.use_intensity else 0)
+    c_hid, c_hbe, c_q, c_x, aw = 0, 64, 64 + WB, 64 + WB + HH, 64 + WB + HH + D * W
+    A = d["acts"].double().cpu()
+    G = d["gacts"].double().cpu()
+    r16 = lambda t: t.float().to(torch.bfloat16).double()
+    wt = lambda m: r16(m.weight.detach().cpu())
+    p_ = cfg.rgb_padding
+    g_rgb = cot["rgb"].reshape(M, 3).double().cpu()
+    sg = (d["rgb"].double().cpu().t() + p_) / (1 + 2 * p_)
+    d_o = g_rgb * (1 + 2 * p_) * sg * (1 - sg) * cfg.rgb_premultiplier
+    want = {}
+    dz = (A[:, c_x + (D - 1) * W:c_x + D * W] > 0) * (r16(d_o) @ wt(fus.rgb_layer))
+    want[c_x + (D - 1) * W] = dz
+    for l in range(D - 1, 1, -1):
+        dz = (A[:, c_x + (l - 1) * W:c_x + l * W] > 0) * (r16(dz) @ wt(getattr(fus, f"lin_second_stage_{l}")))
+        want[c_x + (l - 1) * W] = dz
+    dz1 = r16(dz)
+    W1, W0 = wt(fus.lin_second_stage_1), wt(fus.lin_second_stage_0)
+    dz0 = (A[:, c_x:c_x + W] > 0) * (dz1 @ W1[:, :W])
+    want[c_x] = dz0
+    dhbe = dz1 @ W1[:, W:W + WB] + r16(dz0) @ W0[:, :WB]
+    if HH:
+        dlo = torch.zeros(M, 32, dtype=torch.float64)
+        if K:
+            pr = d["sem"].double().cpu().t()
+            gs = cot["semantic"].reshape(M, K).double().cpu()
+            dlo[:, :K] = pr * (gs - (pr * gs).sum(-1, keepdim=True))
+        if cfg.use_intensity:
+            dlo[:, K] = cot["intensity"].reshape(M).double().cpu()
+        np.testing.assert_allclose(G[:, aw:aw + 32].numpy(), r16(dlo).numpy(), rtol=1e-2, atol=1e-6 * float(dlo.abs().max()))
+        h1 = torch.cat(([wt(fus.sem_layer[0])] if K else []) + ([wt(fus.intensity_layer[0])] if cfg.use_intensity else []), 0)
+        h2 = torch.zeros(32, HH, dtype=torch.float64)
+        r0 = 0
+        if K:
+            h2[:K, :64] = wt(fus.sem_layer[2])
+            r0 = 64
+        if cfg.use_intensity:
+            h2[K, r0:r0 + 64] = wt(fus.intensity_layer[2])[0]
+        dq = (A[:, c_q:c_q + HH] > 0) * (r16(dlo) @ h2)
+        want[c_q] = dq
+        dhbe = dhbe + r16(dq) @ h1
+    dr = cot["density"].reshape(M).double().cpu() * (1 - torch.exp(-d["density"].double().cpu()))
+    dhbe[:, 0] += dr
+    want[c_hbe] = dhbe
+    dhid = (A[:, c_hid:c_hid + 64] > 0) * (r16(dhbe) @ wt(fus.density_layer[2]))
+    want[c_hid] = dhid
+    dfeat = r16(dhid) @ wt(fus.density_layer[0])
+    for c0, w in want.items():
+        close(f"gacts[{c0}:{c0 + w.shape[1]}]", G[:, c0:c0 + w.shape[1]].numpy(), w.numpy(), 4e-3)
+    close("d_feat", d["d_feat"].double().cpu().numpy(), dfeat.numpy(), 4e-3)
+    torch.set_grad_enabled(True)
+
+    # (3) end to end against autograd through the bf16-operand torch model: on top of (2), the two forwards differ in f32
+    # accumulation order, a few activations round to the other bf16 neighbour, and ~3e-4 of the ReLU masks flip
+    for (name, p), (_, pf) in zip(ref.named_parameters(), fus.named_parameters()):
+        if p.grad is None:  # a layer the configuration builds but does not read (sem_layer without use_semantic)
+            assert pf.grad is None, name
+            continue
+        assert pf.grad is not None, name
+        close("grad " + name, pf.grad.float().cpu().numpy(), p.grad.float().cpu().numpy(), 4e-2)
+    # and it trains: a few Adam steps on the fused level lower a depth + rgb loss
+    opt = torch.optim.Adam(fus.parameters(), lr=2e-3)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        r, _ = fus.render(batch, tdist)
+        loss = ((r["depth"] - 0.7) ** 2).mean() + ((r["rgb"] - 0.25) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
