@@ -630,18 +630,23 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
                 for (int jb = 0; jb < 2; ++jb) {
                     const uint32_t piece = 8 * t + 4 * jb + q;  // float4 index inside the feature row
                     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (4 * piece + 4 <= P.F) {
-                        if (staged) v = *reinterpret_cast<const f32x4 *>(stg + (piece * 64 + idx) * 4);
-                        else
-                            v = P.feat_piece_major ? *reinterpret_cast<const f32x4 *>(P.feat + ((size_t)piece * P.M + sc) * 4)
-                                                   : *reinterpret_cast<const f32x4 *>(P.feat + (size_t)sc * P.F + 4 * piece);
+                    if (COMP || staged) {
+                        // branch-free: the pieces past F read a valid staged piece and are zeroed by a select (`piece` depends
+                        // on the lane, a branch here is a divergent one in front of every trunk)
+                        const bool ok = 4 * piece + 4 <= P.F;
+                        const f32x4 w = *reinterpret_cast<const f32x4 *>(stg + ((ok ? piece : 0u) * 64 + idx) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ok ? w[e] : 0.0f;
+                    } else if (4 * piece + 4 <= P.F) {
+                        v = P.feat_piece_major ? *reinterpret_cast<const f32x4 *>(P.feat + ((size_t)piece * P.M + sc) * 4)
+                                               : *reinterpret_cast<const f32x4 *>(P.feat + (size_t)sc * P.F + 4 * piece);
                     }
                     fin[t].a[jb][n] = v;
                 }
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (staged) v = *reinterpret_cast<const f32x4 *>(stg + NLR_STAGE_ENC + (((2 * h + n) * 2 + jb) * 4 + q) * 4);
+                if (COMP || staged) v = *reinterpret_cast<const f32x4 *>(stg + NLR_STAGE_ENC + (((2 * h + n) * 2 + jb) * 4 + q) * 4);
                 else if (P.rgb) v = *reinterpret_cast<const f32x4 *>(P.enc + (size_t)(sc / P.S) * 32 + 16 * jb + 4 * q);
                 encu.a[jb][n] = v;
             }
