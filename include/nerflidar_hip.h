@@ -325,6 +325,56 @@ int nlr_mlp_train_backward(const NlrTrainPlan *p, uint32_t M, uint32_t S, const 
 int nlr_box_winner(const float *tdist, const float *origins, const float *directions, const float *box_params, uint32_t N,
                    uint32_t S, uint32_t n_obj, int32_t *winner, void *stream);
 
+/* (7b) The whole branch on the device, no host synchronisation anywhere (Config.instance_obj = True in latent mode, the shipped
+ *      gin: one ObjMLP per class + one latent code per track, ZI/models.py:125-142,401-477).
+ *
+ * nlr_track_box_params <-> get_pose (ZI/obj_utils.py:431-475) + the per-(ray, track) constants of world2object
+ *      (obj_utils.py:116-176): blend of the two recorded poses closest in time to the ray's timestamp, then
+ *      (cos theta, sin theta, t_w_o, scale) as nlr_box_winner takes them.  tracks dev f32 [n_obj, T, 9] =
+ *      (center3, theta_z, wlh3, timestamp, track id), T >= 2; timestamps dev f32 [N]; box_params dev f32 [N, n_obj, 8].
+ *
+ * NlrObjects: the packed object networks (owned, like NlrModel).  Each class: an L x C hash grid on box coordinates (bound 1,
+ *      no erf re-weighting), density_layer (L*C + shape half of the latent -> 64 -> bottleneck <= 64), view MLP of width <= 32
+ *      on [bottleneck | pos_enc(box-frame view direction, deg_view) | texture half of the latent] with the skip concatenation
+ *      after layer `skip_layer_dir`, rgb layer; semantic = one-hot of `class_type` (fixed_semantic; 255 = all zeros).
+ *      NlrMlpDesc carries grid, density0/2, view[], rgb_layer and the scalars; its sem/intensity members are ignored.
+ *
+ * nlr_objects_apply: winner (see nlr_box_winner) -> per-class lists of the owned samples (device-side compaction) -> the
+ *      class's network on them -> results written over density [N,S], rgb [3,N,S] and semantic [K,N,S] in place (rgb and
+ *      semantic may be NULL: proposal levels replace the density only, models.py:466-477).  workspace: dev, at least
+ *      nlr_objects_workspace_bytes(o, N, S) bytes.  winner_out [N,S] int32 optional.
+ *
+ * nlr_render_rays_dynamic: nlr_render_rays with the object merge between the MLP and the compositing of every level.
+ *      `winner` (optional) receives one [N, S_l] int32 owner map per level (ray_history's obj_mask = winner >= 0).
+ *      workspace: nlr_workspace_bytes(m, N) + nlr_objects_workspace_bytes(o, N, max S). */
+int nlr_track_box_params(const float *tracks, const float *timestamps, uint32_t N, uint32_t n_obj, uint32_t T, float *box_params,
+                         void *stream);
+
+typedef struct NlrObjClassDesc {
+    NlrMlpDesc mlp;
+    uint32_t latent_size, split_latent;  /* Config.latent_size (0 = none), MLP.split_latent (models.py:881-885,924-925) */
+    int32_t class_type;                  /* label of the fixed one-hot semantic, 255 = none (models.py:1124-1130) */
+} NlrObjClassDesc;
+
+typedef struct NlrObjectsDesc {
+    uint32_t n_classes;
+    const NlrObjClassDesc *classes;
+    uint32_t n_tracks;
+    const int32_t *track_class;          /* HOST [n_tracks]: index into `classes` */
+    const float *latents;                /* HOST f32 [n_tracks, latent_size] (latent_vector_dict), NULL when latent_size = 0 */
+} NlrObjectsDesc;
+
+typedef struct NlrObjects NlrObjects;
+int nlr_objects_create(const NlrObjectsDesc *desc, NlrObjects **out, void *stream);
+void nlr_objects_destroy(NlrObjects *o);
+size_t nlr_objects_workspace_bytes(const NlrObjects *o, uint32_t N, uint32_t S);
+int nlr_objects_apply(const NlrObjects *o, const NlrRays *rays, const float *tdist, const float *box_params, uint32_t N, uint32_t S,
+                      uint32_t n_obj, float *density, float *rgb, float *semantic, uint32_t K, int32_t *winner_out, void *workspace,
+                      size_t workspace_bytes, void *stream);
+int nlr_render_rays_dynamic(const NlrModel *m, const NlrObjects *o, const NlrRays *rays, const float *box_params, uint32_t n_obj,
+                            uint32_t N, const NlrRenderCfg *cfg, const NlrOut *out, int32_t *const *winner, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "nlr_kernels.h"
+#include "nlr_objects.h"
 
 
 static thread_local char g_err[512] = "";
@@ -568,16 +569,33 @@ extern "C" int nlr_mlp_level(const NlrModel *m, uint32_t level, const NlrRays *r
 }
 
 // ---- Model.forward ----------------------------------------------------------------------------------
-extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t N, const NlrRenderCfg *cfg, const NlrOut *out,
-                               void *workspace, size_t workspace_bytes, void *stream) {
+// The dynamic-object branch of one call (ZI/models.py:401-477): between the MLP and the compositing of every level the samples
+// inside a track's box take that track's ObjMLP results.
+struct DynScene {
+    const NlrObjects *objs;
+    const float *box_params;
+    uint32_t n_obj;
+    int32_t *const *winner;  // optional per-level owner maps
+};
+
+static int render_impl(const NlrModel *m, const NlrRays *rays, uint32_t N, const NlrRenderCfg *cfg, const NlrOut *out, void *workspace,
+                       size_t workspace_bytes, void *stream, const DynScene *dyn) {
     NLR_CHECK_ARG(m && rays && cfg && out, "render_rays: NULL argument");
     NLR_CHECK_ARG(rays->origins && rays->directions && rays->near && rays->far && rays->radii, "render_rays: ray batch has NULL tensors");
     if (N == 0) return NLR_OK;
-    const size_t need = nlr_workspace_bytes(m, N);
+    size_t need = nlr_workspace_bytes(m, N), obj_ws = 0;
+    if (dyn) {
+        uint32_t smax = 0;
+        for (uint32_t l = 0; l < m->num_levels; ++l) smax = m->lv[l].S > smax ? m->lv[l].S : smax;
+        obj_ws = nlr_objects_workspace_bytes(dyn->objs, N, smax);
+        need += obj_ws;
+    }
     if (!workspace || workspace_bytes < need)
-        NLR_FAIL(NLR_ERR_WORKSPACE, "render_rays: workspace %zu B < nlr_workspace_bytes() = %zu B", workspace_bytes, need);
+        NLR_FAIL(NLR_ERR_WORKSPACE, "render_rays: workspace %zu B < %zu B (nlr_workspace_bytes%s)", workspace_bytes, need,
+                 dyn ? " + nlr_objects_workspace_bytes" : "");
     hipStream_t st = (hipStream_t)stream;
-    Carve c(workspace, workspace_bytes);
+    void *obj_space = dyn ? (char *)workspace + (workspace_bytes - obj_ws) : nullptr;  // the tail of the workspace
+    Carve c(workspace, workspace_bytes - obj_ws);
     const uint32_t n = cfg->sample_n ? cfg->sample_n : 7, mloops = cfg->sample_m ? cfg->sample_m : 3;
 
     const float *prev_s = nullptr, *prev_w = nullptr;
@@ -609,7 +627,7 @@ extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t 
         float *feat = nullptr, *rb = nullptr, *rgb = nullptr, *sem = nullptr, *inten = nullptr, *seg = nullptr, *dnorm = nullptr;
         // Compositing mode: nobody asked for the per-sample heads of the last level (ray_history), so the MLP kernel composites
         // inside its 32-sample segments and 24 floats per sample never go to HBM.
-        const bool fuse = last && !lv.is_prop && !ho.rgb && !ho.semantic && !ho.intensity && lv.gp.C == 4 && n <= 8 &&
+        const bool fuse = !dyn && last && !lv.is_prop && !ho.rgb && !ho.semantic && !ho.intensity && lv.gp.C == 4 && n <= 8 &&
                           nlr_mlp_can_composite(lv.W, lv.WB, lv.HT, lv.prec, lv.F, S, lv.K, lv.use_int, (uint64_t)N * S);
         if (!lv.is_prop) {
             feat = c.take((size_t)N * S * lv.F + 256);
@@ -626,6 +644,11 @@ extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t 
         rc = run_mlp_level(m, lv, rays, tdist, N, n, mloops, cfg->rand_deg[l], feat, rb, density, rgb, sem, inten, nullptr, st, true, seg,
                            dnorm);
         if (rc) return rc;
+        if (dyn) {  // (the object networks have no intensity head: DynamicModel refuses use_intensity, like the reference's merge)
+            rc = nlr_objects_apply_impl(dyn->objs, rays, tdist, dyn->box_params, N, S, dyn->n_obj, density, rgb, sem, lv.K,
+                                        dyn->winner ? dyn->winner[l] : nullptr, obj_space, obj_ws, st);
+            if (rc) return rc;
+        }
         {
             ProfScope ps(&m->prof, NLR_K_COMPOSITE, st);
             if (fuse)
@@ -653,6 +676,21 @@ extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t 
         prev_w = weights;
         n_prev = S;
     }
-    if (c.off > workspace_bytes) NLR_FAIL(NLR_ERR_WORKSPACE, "render_rays: carved %zu B > workspace %zu B", c.off, workspace_bytes);
+    if (c.off > workspace_bytes - obj_ws) NLR_FAIL(NLR_ERR_WORKSPACE, "render_rays: carved %zu B > workspace %zu B", c.off, workspace_bytes - obj_ws);
     return NLR_OK;
+}
+
+extern "C" int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t N, const NlrRenderCfg *cfg, const NlrOut *out,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    return render_impl(m, rays, N, cfg, out, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int nlr_render_rays_dynamic(const NlrModel *m, const NlrObjects *o, const NlrRays *rays, const float *box_params, uint32_t n_obj,
+                                       uint32_t N, const NlrRenderCfg *cfg, const NlrOut *out, int32_t *const *winner, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+    NLR_CHECK_ARG(m && o && (box_params || n_obj == 0), "render_rays_dynamic: NULL argument");
+    for (uint32_t l = 0; l < m->num_levels; ++l)
+        NLR_CHECK_ARG(!m->lv[l].use_int, "render_rays_dynamic: the object networks have no intensity head (ZI/models.py:469 assigns None)");
+    DynScene d{o, box_params, n_obj, winner};
+    return render_impl(m, rays, N, cfg, out, workspace, workspace_bytes, stream, &d);
 }

@@ -11,12 +11,9 @@
 // 7-sample mean [N*S, L*C] leaves the kernel (NerfMLP level) or only the density (proposal levels).
 #include "nlr_kernels.h"
 
-#include <hip/hip_fp16.h>
+#include "nlr_grid_level.h"
 
 
-struct Gauss {  // one contracted multisample, mapped to the unit cube
-    float x0, x1, x2, zs;
-};
 
 __device__ __forceinline__ Gauss nlr_cast_one(const CastParams &cp, uint32_t ray, uint32_t k, uint32_t j, float t0, float t1,
                                               const float *o, const float *d, const float *bx, const float *by, float radius,
@@ -62,59 +59,6 @@ __device__ __forceinline__ Gauss nlr_cast_one(const CastParams &cp, uint32_t ray
         raw[2] = m[2] / 2.0f;
     }
     return g;
-}
-
-template <typename T>
-__device__ __forceinline__ float nlr_ld(const T *p);
-template <>
-__device__ __forceinline__ float nlr_ld<float>(const float *p) { return *p; }
-template <>
-__device__ __forceinline__ float nlr_ld<__half>(const __half *p) { return __half2float(*p); }
-
-// Trilinear interpolation of C channels at one level (gridencoder.cu:137-197); acc += w_erf * value.
-template <typename T, int C, int MODE>
-__device__ __forceinline__ void nlr_level_accum_m(const GridParams &gp, uint32_t level, const Gauss &g, float werf, float (&acc)[C]) {
-    if ((g.x0 < 0 || g.x0 > 1) || (g.x1 < 0 || g.x1 > 1) || (g.x2 < 0 || g.x2 > 1)) return;  // zeros
-    const T *grid = (const T *)gp.table + (size_t)gp.offset[level] * C;
-    const float scale = gp.scale[level];
-    const float half = gp.align_corners ? 0.0f : 0.5f;
-    float pos[3] = {fmaf(g.x0, scale, half), fmaf(g.x1, scale, half), fmaf(g.x2, scale, half)};
-    uint32_t pg[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        pg[d] = (uint32_t)floorf(pos[d]);
-        pos[d] -= (float)pg[d];
-        if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
-    }
-    uint32_t idx[8];
-    nlr_corner_idx<MODE>(gp, level, pg, idx);
-    float v[8][C];
-#pragma unroll
-    for (int c8 = 0; c8 < 8; ++c8)
-#pragma unroll
-        for (int c = 0; c < C; ++c) v[c8][c] = nlr_ld<T>(grid + (size_t)idx[c8] * C + c);
-    // corner weights in the reference's multiplication order ((wx * wy) * wz)
-    const float wx[2] = {1 - pos[0], pos[0]}, wy[2] = {1 - pos[1], pos[1]}, wz[2] = {1 - pos[2], pos[2]};
-    float r[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) r[c] = 0.0f;
-#pragma unroll
-    for (int c8 = 0; c8 < 8; ++c8) {
-        const float w = (wx[c8 & 1] * wy[(c8 >> 1) & 1]) * wz[(c8 >> 2) & 1];
-#pragma unroll
-        for (int c = 0; c < C; ++c) r[c] = fmaf(w, v[c8][c], r[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] += r[c] * werf;
-}
-
-// `mode` is wave-uniform (a property of the level)
-template <typename T, int C>
-__device__ __forceinline__ void nlr_level_accum(const GridParams &gp, uint32_t level, const Gauss &g, float werf, float (&acc)[C]) {
-    const uint32_t mode = gp.mode[level];
-    if (mode == 0) nlr_level_accum_m<T, C, 0>(gp, level, g, werf, acc);
-    else if (mode == 1) nlr_level_accum_m<T, C, 1>(gp, level, g, werf, acc);
-    else nlr_level_accum_m<T, C, 2>(gp, level, g, werf, acc);
 }
 
 // models.py:976: erf(1 / clamp(sqrt(8 * std^2 * G^2), min=1e-10))

@@ -38,6 +38,15 @@ class NlrMlpDesc(C.Structure):
                 ("rgb_bias", C.c_float), ("rgb_padding", C.c_float), ("re_weights", C.c_uint32)]
 
 
+class NlrObjClassDesc(C.Structure):
+    _fields_ = [("mlp", NlrMlpDesc), ("latent_size", C.c_uint32), ("split_latent", C.c_uint32), ("class_type", C.c_int32)]
+
+
+class NlrObjectsDesc(C.Structure):
+    _fields_ = [("n_classes", C.c_uint32), ("classes", C.POINTER(NlrObjClassDesc)), ("n_tracks", C.c_uint32), ("track_class", c_fp),
+                ("latents", c_fp)]
+
+
 class NlrModelDesc(C.Structure):
     _fields_ = [("num_levels", C.c_uint32), ("num_samples", C.c_uint32 * NLR_MAX_LEVELS),
                 ("mlps", C.POINTER(NlrMlpDesc) * NLR_MAX_LEVELS), ("dilation_multiplier", C.c_float),
@@ -74,6 +83,8 @@ EXPORTS = ["nlr_last_error", "nlr_version", "nlr_grid_encode_forward", "nlr_grid
            "nlr_render_rays", "nlr_kernel_names", "nlr_resample_level", "nlr_mlp_level", "nlr_composite_level",
            "nlr_profile_begin", "nlr_profile_end", "nlr_range_workspace_bytes", "nlr_range_project",
            "nlr_composite_backward", "nlr_hash_decay_forward", "nlr_hash_decay_backward", "nlr_box_winner", "nlr_cast_contract",
+           "nlr_track_box_params", "nlr_objects_create", "nlr_objects_destroy", "nlr_objects_workspace_bytes", "nlr_objects_apply",
+           "nlr_render_rays_dynamic",
            "nlr_train_plan_create", "nlr_train_plan_destroy", "nlr_train_act_width", "nlr_train_param_layout", "nlr_train_pack",
            "nlr_mlp_train_forward", "nlr_mlp_train_backward"]
 NLR_K_COUNT = 6
@@ -125,6 +136,16 @@ def lib():
         L.nlr_cast_contract.argtypes = [C.POINTER(NlrRays), c_fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, c_fp, c_fp, c_fp,
                                         c_fp]
         L.nlr_box_winner.argtypes = [c_fp, c_fp, c_fp, c_fp, C.c_uint32, C.c_uint32, C.c_uint32, c_fp, c_fp]
+        L.nlr_track_box_params.argtypes = [c_fp, c_fp, C.c_uint32, C.c_uint32, C.c_uint32, c_fp, c_fp]
+        L.nlr_objects_create.argtypes = [C.POINTER(NlrObjectsDesc), C.POINTER(c_fp), c_fp]
+        L.nlr_objects_destroy.restype = None
+        L.nlr_objects_destroy.argtypes = [c_fp]
+        L.nlr_objects_workspace_bytes.restype = C.c_size_t
+        L.nlr_objects_workspace_bytes.argtypes = [c_fp, C.c_uint32, C.c_uint32]
+        L.nlr_objects_apply.argtypes = [c_fp, C.POINTER(NlrRays), c_fp, c_fp, C.c_uint32, C.c_uint32, C.c_uint32, c_fp, c_fp, c_fp,
+                                        C.c_uint32, c_fp, c_fp, C.c_size_t, c_fp]
+        L.nlr_render_rays_dynamic.argtypes = [c_fp, c_fp, C.POINTER(NlrRays), c_fp, C.c_uint32, C.c_uint32, C.POINTER(NlrRenderCfg),
+                                              C.POINTER(NlrOut), C.POINTER(c_fp), c_fp, C.c_size_t, c_fp]
         L.nlr_train_plan_create.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int] + [C.c_float] * 4 + [C.POINTER(c_fp), C.POINTER(C.c_uint32)]
         L.nlr_train_plan_destroy.restype = None
         L.nlr_train_plan_destroy.argtypes = [c_fp]

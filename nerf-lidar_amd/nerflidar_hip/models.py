@@ -155,6 +155,13 @@ class Model:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def _render_call(self, rays, n: int, cfg, out) -> None:
+        """The library call of `render_rays` (DynamicModel substitutes nlr_render_rays_dynamic)."""
+        ws = self._workspace(n)
+        rc = _lib.lib().nlr_render_rays(self._handle, C.byref(rays), n, C.byref(cfg), C.byref(out), _lib.ptr(ws), ws.numel(),
+                                        _lib.current_stream())
+        _lib.check(rc, "nlr_render_rays")
+
     def render_rays(self, batch: Dict[str, torch.Tensor], train_frac: float = 1.0, compute_extras: bool = True,
                     sample_n: int = 7, sample_m: int = 3, want_history: bool = False, scale_factor: float = 0.0,
                     rand_jitter: Optional[List[torch.Tensor]] = None, rand_deg: Optional[List[torch.Tensor]] = None,
@@ -236,10 +243,7 @@ class Model:
                 keep.append(t)
                 cfg.rand_deg[li] = t.data_ptr()
         with torch.cuda.device(dev):
-            ws = self._workspace(n)
-            rc = _lib.lib().nlr_render_rays(self._handle, C.byref(rays), n, C.byref(cfg), C.byref(out),
-                                            _lib.ptr(ws), ws.numel(), _lib.current_stream())
-        _lib.check(rc, "nlr_render_rays")
+            self._render_call(rays, n, cfg, out)
         if want_history:  # back to the reference's [N, S, C] layout (ZI/models.py:553-557)
             last = hist[-1]
             last["rgb"] = last["rgb"].permute(1, 2, 0)

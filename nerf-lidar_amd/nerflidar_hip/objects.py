@@ -195,6 +195,92 @@ class DynamicModel(Model):
         self.latents = [torch.from_numpy(np.ascontiguousarray(sd[f"latent_vector_dict.obj_latent_{t}"], np.float32)).to(self.device)
                         for t in range(len(self.class_ids))] if lat > 0 else [None] * len(self.class_ids)
         self._latent_table = torch.stack(self.latents) if lat > 0 else None
+        self._objects = C.c_void_p(None)
+        self._build_native(sd, lat)
+
+    def _build_native(self, sd, lat: int) -> None:
+        """Pack the object networks for the device-side branch (`nlr_objects_create`, header section 7b)."""
+        n_cls = len(self._class_list)
+        descs = (_lib.NlrObjClassDesc * n_cls)()
+        for i, cid in enumerate(self._class_list):
+            net = self.obj_mlps[cid]
+            # grid + Linear stack through Model's descriptor assembly; the table is the ObjMLP encoder's own parameter
+            md = self._mlp_desc(net.prefix, net.cfg, sd, torch.float32)
+            md.grid.table = net.encoder.embeddings.data_ptr()
+            self.tables.pop(net.prefix, None)
+            descs[i].mlp = md
+            descs[i].latent_size, descs[i].split_latent = lat, int(net.cfg.split_latent)
+            descs[i].class_type = int(net.cfg.class_type)
+        tc = np.ascontiguousarray([self._class_list.index(c) for c in self.class_ids], np.int32)
+        lt = np.ascontiguousarray(self._latent_table.cpu().numpy(), np.float32) if lat > 0 else None
+        od = _lib.NlrObjectsDesc()
+        od.n_classes, od.classes = n_cls, descs
+        od.n_tracks, od.track_class = len(self.class_ids), tc.ctypes.data
+        od.latents = lt.ctypes.data if lt is not None else None
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().nlr_objects_create(C.byref(od), C.byref(self._objects), _lib.current_stream())
+        self._keep.clear()
+        _lib.check(rc, "nlr_objects_create")
+
+    def __del__(self):
+        try:
+            if self._objects:
+                _lib.lib().nlr_objects_destroy(self._objects)
+                self._objects = C.c_void_p(None)
+            Model.__del__(self)
+        except Exception:  # (interpreter shutdown: module globals may already be gone)
+            pass
+
+    def _workspace(self, n: int) -> torch.Tensor:
+        L = _lib.lib()
+        need = L.nlr_workspace_bytes(self._handle, n) + L.nlr_objects_workspace_bytes(self._objects, n, max(self.mc.level_samples()))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _render_call(self, rays, n: int, cfg, out) -> None:
+        box, winners = self._dyn_call
+        ws = self._workspace(n)
+        wp = (_lib.c_fp * len(winners))(*[w.data_ptr() for w in winners]) if winners else None
+        rc = _lib.lib().nlr_render_rays_dynamic(self._handle, self._objects, C.byref(rays), _lib.ptr(box), int(box.shape[1]), n, C.byref(cfg),
+                                                C.byref(out), wp, _lib.ptr(ws), ws.numel(), _lib.current_stream())
+        _lib.check(rc, "nlr_render_rays_dynamic")
+
+    def box_params(self, timestamp: torch.Tensor, curr_track=None) -> torch.Tensor:
+        """[N, n_obj, 8] world -> box constants of every ray and track at the ray's timestamp (`nlr_track_box_params`:
+        get_pose + the constants of world2object, obj_utils.py:431-475,116-176)."""
+        if curr_track is None:
+            curr_track = getattr(self, "_track_override", None)
+        tracks = self.tracks if curr_track is None else torch.as_tensor(curr_track, device=self.device, dtype=torch.float32)
+        tracks = tracks.contiguous()
+        ts = timestamp.reshape(-1).to(self.device, torch.float32).contiguous()
+        box = torch.empty(ts.shape[0], tracks.shape[0], 8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().nlr_track_box_params(_lib.ptr(tracks), _lib.ptr(ts), ts.shape[0], tracks.shape[0], tracks.shape[1],
+                                                       _lib.ptr(box), _lib.current_stream()), "nlr_track_box_params")
+        return box
+
+    @torch.no_grad()
+    def render_rays(self, batch, train_frac: float = 1.0, compute_extras: bool = True, sample_n: int = 7, sample_m: int = 3,
+                    want_history: bool = False, scale_factor: float = 0.0, rand_jitter=None, rand_deg=None, packed=None, curr_track=None):
+        """`Model.render_rays` with the object merge of ZI/models.py:401-477 inside every level, all on the device
+        (`nlr_render_rays_dynamic`): pose blend, owner map, per-class compaction and the object networks run as kernels on
+        the render stream; nothing is read back.  History entries carry `obj_mask` (winner >= 0) as the reference's
+        ray_results do."""
+        if "timestamp" not in batch:
+            raise RuntimeError("batch['timestamp'] is missing (ZI/models.py:315)")
+        n = batch["origins"].shape[0]
+        box = self.box_params(batch["timestamp"], curr_track)
+        winners = [torch.empty(n, S, dtype=torch.int32, device=self.device) for S in self.mc.level_samples()]
+        self._dyn_call = (box, winners)
+        try:
+            r, hist = Model.render_rays(self, batch, train_frac, compute_extras, sample_n, sample_m, want_history, scale_factor, rand_jitter,
+                                        rand_deg, packed)
+        finally:
+            self._dyn_call = None
+        for h, w in zip(hist, winners):
+            h["obj_mask"] = w >= 0
+        return r, hist
 
     def forward(self, rand, batch, train_frac, compute_extras, zero_glo=True, sample_n=7, sample_m=3, step=0, max_step=25000,
                 curr_track=None):
@@ -207,9 +293,11 @@ class DynamicModel(Model):
 
     __call__ = forward
 
-    # -- the reference's level loop, stage by stage (what nlr_render_rays does in one call, plus the object merge) ---------------
+    # -- the reference's level loop, stage by stage, with the object networks as torch ops: the round-1 form of this branch,
+    # kept as an independent second implementation (tests compare the two; it also serves object configurations outside
+    # nlr_objects_create's envelope) ---------------
     @torch.no_grad()
-    def render_rays(self, batch, train_frac: float = 1.0, compute_extras: bool = True, sample_n: int = 7, sample_m: int = 3,
+    def render_rays_torch(self, batch, train_frac: float = 1.0, compute_extras: bool = True, sample_n: int = 7, sample_m: int = 3,
                     want_history: bool = False, scale_factor: float = 0.0, rand_jitter=None, rand_deg=None, curr_track=None):
         if rand_jitter is not None or rand_deg is not None:
             raise NotImplementedError("DynamicModel renders deterministically (rand=False), as render_lidar does")

@@ -17,10 +17,13 @@ mc.config.instance_obj = True
 dyn = nobj.DynamicModel(mc, sd, tracks, names[:n_tracks], precision=2)
 static = Model(nconfig.workload("REF"), sd, precision=2)
 batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
-for name, m in (("static fused (nlr_render_rays)", static), (f"dynamic, {n_tracks} tracks (stage loop + ObjMLPs)", dyn)):
-    for _ in range(3): r, h = m.render_rays(batch)
+runs = (("static fused (nlr_render_rays)", static.render_rays),
+        (f"dynamic, {n_tracks} tracks, on the device (nlr_render_rays_dynamic)", dyn.render_rays),
+        (f"dynamic, {n_tracks} tracks, stage loop + torch ObjMLPs (round 1)", dyn.render_rays_torch))
+for name, fn in runs:
+    for _ in range(3): r, h = fn(batch)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): r, h = m.render_rays(batch)
+    for _ in range(10): r, h = fn(batch)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     extra = f", samples in boxes per level {[int(x['obj_mask'].sum()) for x in h]}" if "obj_mask" in h[0] else ""
     print(f"{name}: {dt*1e3:.2f} ms per sweep, {n/dt/1e6:.2f} M rays/s{extra}")
