@@ -78,6 +78,16 @@ int nlr_grid_encode_backward(const float *grad, const float *inputs, const int32
                              uint32_t gridtype, int align_corners, uint32_t interp, int grad_layout,
                              void *stream);
 
+/* nlr_grad_total_variation <-> grad_total_variation (gridencoder.h:15, cu:506-645; bound by grid.py:176-198).
+ *   inputs dev f32 [B, D] already mapped to [0,1] (points outside are skipped); embeddings dev f32 [sO, C];
+ *   grad dev f32 [sO, C] is accumulated into (embeddings.grad, between loss.backward() and optimizer.step()):
+ *   grad[cell] += weight / (2 D) * sum_nb (e[cell] - e[nb]) * rsqrt(sum_nb (e[cell] - e[nb])^2 + 1e-9) over the 2 D axis
+ *   neighbours of the cell corner floor(x * scale + 0.5) that lie inside the level.  f32 tables only (grid.py runs it with
+ *   autocast disabled); float atomics, order not reproducible, like the reference. */
+int nlr_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets_host, float weight,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                             int align_corners, void *stream);
+
 /* Host helper shared with the CPU checker so both use bit-identical level constants
  * (scale = exp2f(l*S)*H - 1, resolution = ceil(scale)+1; cu:138-139). */
 void nlr_level_scale(uint32_t L, float S, uint32_t H, float *scale, uint32_t *resolution);

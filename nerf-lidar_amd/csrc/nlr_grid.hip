@@ -356,3 +356,81 @@ extern "C" int nlr_grid_encode_backward(const float *grad, const float *inputs, 
     }
     return NLR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// total-variation gradient (gridencoder.cu:506-601; grid.py:176-198 calls it between loss.backward() and optimizer.step())
+// ---------------------------------------------------------------------------------------------
+// One thread per (point, level), as the reference: the work per thread is 7 gathers of C values and C atomics; the atomics go to
+// the cell corners the batch happens to draw (distinct addresses in the hashed levels, a few thousand hot cells in the dense ones).
+template <int C>
+__global__ void __launch_bounds__(256) nlr_grid_tv_kernel(const float *__restrict__ x, GridParams gp, float *__restrict__ grad, float weight,
+                                                         uint32_t B) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const float *tb = (const float *)gp.table + (size_t)gp.offset[level] * C;
+    float *gg = grad + (size_t)gp.offset[level] * C;
+    const float x0 = x[(size_t)b * 3 + 0], x1 = x[(size_t)b * 3 + 1], x2 = x[(size_t)b * 3 + 2];
+    if ((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1)) return;
+    const uint32_t hsize = gp.hsize[level], res = gp.res[level];
+    const float scale = gp.scale[level];
+    const float half = gp.align_corners ? 0.0f : 0.5f;
+    uint32_t pg[3] = {(uint32_t)floorf(fmaf(x0, scale, half)), (uint32_t)floorf(fmaf(x1, scale, half)), (uint32_t)floorf(fmaf(x2, scale, half))};
+    float results[C], idelta[C], center[C];
+    const uint32_t index = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pg[0], pg[1], pg[2]) * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+        results[ch] = 0.0f;
+        idelta[ch] = 0.0f;
+        center[ch] = tb[index + ch];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const uint32_t cur = pg[d];
+        if (cur < res) {  // right neighbour
+            pg[d] = cur + 1;
+            const uint32_t ir = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pg[0], pg[1], pg[2]) * C;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                const float g = center[ch] - tb[ir + ch];
+                results[ch] += g;
+                idelta[ch] = fmaf(g, g, idelta[ch]);
+            }
+        }
+        if (cur > 0) {  // left neighbour
+            pg[d] = cur - 1;
+            const uint32_t il = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pg[0], pg[1], pg[2]) * C;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                const float g = center[ch] - tb[il + ch];
+                results[ch] += g;
+                idelta[ch] = fmaf(g, g, idelta[ch]);
+            }
+        }
+        pg[d] = cur;
+    }
+    const float w = weight / 6.0f;  // weight / (2 * D)
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) atomicAdd(gg + index + ch, (w * results[ch]) * __frsqrt_rn(idelta[ch] + 1e-9f));
+}
+
+extern "C" int nlr_grad_total_variation(const float *inputs, const float *embeddings, float *grad, const int32_t *offsets_host, float weight,
+                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                        int align_corners, void *stream) {
+    NLR_CHECK_ARG(D == 3, "GridEncoding: this build supports input_dim D = 3 only (got %u)", D);
+    NLR_CHECK_ARG(inputs && embeddings && grad, "grad_total_variation: NULL tensor");
+    if (B == 0) return NLR_OK;
+    GridParams gp;
+    int rc = nlr_fill_grid_params(&gp, embeddings, 0, offsets_host, L, C, S, H, gridtype, align_corners, 0);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((B + 255) / 256, L), block(256);
+    switch (C) {
+        case 1: hipLaunchKernelGGL(nlr_grid_tv_kernel<1>, grid, block, 0, st, inputs, gp, grad, weight, B); break;
+        case 2: hipLaunchKernelGGL(nlr_grid_tv_kernel<2>, grid, block, 0, st, inputs, gp, grad, weight, B); break;
+        case 4: hipLaunchKernelGGL(nlr_grid_tv_kernel<4>, grid, block, 0, st, inputs, gp, grad, weight, B); break;
+        default: hipLaunchKernelGGL(nlr_grid_tv_kernel<8>, grid, block, 0, st, inputs, gp, grad, weight, B); break;
+    }
+    NLR_LAUNCH_CHECK("nlr_grid_tv_kernel");
+    return NLR_OK;
+}

@@ -78,7 +78,7 @@ class NlrOut(C.Structure):
 
 _lib = None
 
-EXPORTS = ["nlr_last_error", "nlr_version", "nlr_grid_encode_forward", "nlr_grid_encode_backward", "nlr_level_scale",
+EXPORTS = ["nlr_last_error", "nlr_version", "nlr_grid_encode_forward", "nlr_grid_encode_backward", "nlr_grad_total_variation", "nlr_level_scale",
            "nlr_sample_u", "nlr_model_create", "nlr_model_destroy", "nlr_model_set_table", "nlr_workspace_bytes",
            "nlr_render_rays", "nlr_kernel_names", "nlr_resample_level", "nlr_mlp_level", "nlr_composite_level",
            "nlr_profile_begin", "nlr_profile_end", "nlr_range_workspace_bytes", "nlr_range_project",
@@ -116,6 +116,8 @@ def lib():
         L.nlr_grid_encode_backward.argtypes = [c_fp, c_fp, c_fp, c_fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.c_float, C.c_uint32, c_fp, c_fp, C.c_uint32, C.c_int, C.c_uint32,
                                                C.c_int, c_fp]
+        L.nlr_grad_total_variation.argtypes = [c_fp, c_fp, c_fp, c_fp, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
+                                               C.c_uint32, C.c_uint32, C.c_int, c_fp]
         L.nlr_render_rays.argtypes = [c_fp, C.POINTER(NlrRays), C.c_uint32, C.POINTER(NlrRenderCfg), C.POINTER(NlrOut),
                                       c_fp, C.c_size_t, c_fp]
         L.nlr_resample_level.argtypes = [c_fp, c_fp, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, c_fp, c_fp,

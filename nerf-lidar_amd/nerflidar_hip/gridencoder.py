@@ -45,7 +45,7 @@ def _host_offsets(offsets) -> torch.Tensor:
 
 
 class _Backend:
-    """Positional signatures of the pybind module `_gridencoder` (gridencoder.h:12-13) + one trailing layout switch:
+    """Positional signatures of the pybind module `_gridencoder` (gridencoder.h:12-15) + one trailing layout switch:
     0 = the reference's [L, B, C] outputs / gradients, 1 = [B, L*C] (what `GridEncoder.forward` returns anyway)."""
 
     @staticmethod
@@ -76,6 +76,18 @@ class _Backend:
             _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(off), _lib.ptr(grad_embeddings), B, D, C, L, float(S), int(H),
             _lib.ptr(dy_dx), _lib.ptr(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp),
             int(grad_layout), _lib.current_stream()), "grid_encode_backward")
+
+    @staticmethod
+    def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
+        _device_operand(inputs, "inputs")
+        _device_operand(embeddings, "embeddings")
+        _device_operand(grad, "grad")
+        if not (inputs.dtype == embeddings.dtype == grad.dtype == torch.float32):
+            raise RuntimeError("grad_total_variation runs in float32 (grid.py:176 disables autocast for it)")
+        off = _host_offsets(offsets)
+        _lib.check(_lib.lib().nlr_grad_total_variation(
+            _lib.ptr(inputs), _lib.ptr(embeddings), _lib.ptr(grad), _lib.ptr(off), float(weight), B, D, C, L, float(S), int(H),
+            int(gridtype), int(bool(align_corners)), _lib.current_stream()), "grad_total_variation")
 
 
 _backend = _Backend()
@@ -187,3 +199,17 @@ class GridEncoder(nn.Module):
         feats = grid_encode(x01, self.embeddings, self._spec, self.per_level_scale, self.base_resolution,
                             x01.requires_grad)
         return feats.reshape(*lead, self.output_dim)
+
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        """grid.py:176-198: add the total-variation gradient of the cells under `inputs` (default: B uniform random points) to
+        `embeddings.grad`; call it after loss.backward() and before optimizer.step()."""
+        if self.embeddings.grad is None:
+            raise ValueError('grad is None, should be called after loss.backward() and before optimizer.step()!')
+        table = self.embeddings
+        if inputs is None:
+            x01 = torch.rand(B, self.input_dim, device=table.device)
+        else:
+            x01 = ((inputs + bound) / (2 * bound)).reshape(-1, self.input_dim).float().contiguous()
+        _backend.grad_total_variation(x01, table.detach().contiguous(), table.grad, self._offsets_host, weight, x01.shape[0],
+                                      self.input_dim, table.shape[1], self.num_levels, math.log2(self.per_level_scale),
+                                      self.base_resolution, self.gridtype_id, self.align_corners)

@@ -12,6 +12,7 @@
  *   NeRF_LiDAR/zipnerf/gridencoder/src/gridencoder.cu:87-245   kernel_grid (forward + dy_dx)
  *   NeRF_LiDAR/zipnerf/gridencoder/src/gridencoder.cu:248-340  kernel_grid_backward
  *   NeRF_LiDAR/zipnerf/gridencoder/src/gridencoder.cu:343-369  kernel_input_backward
+ *   NeRF_LiDAR/zipnerf/gridencoder/src/gridencoder.cu:506-601  kernel_grad_tv
  * Parity status for this file alone: "parity unpinned" against the CUDA binary (it cannot
  * run); it is pinned indirectly through the reference's Python call sites (grid.py:158-174,
  * models.py:974-979), which consume its output in every whole-forward golden fixture.
@@ -216,6 +217,64 @@ void nlr_oracle_grid_backward(const float *grad, const float *inputs, const int3
                 for (uint32_t ch = 0; ch < C; ch++)
                     r += grad[((size_t)l * B + b) * C + ch] * dd[l * D * C + d * C + ch];
             grad_inputs[t] = r;
+        }
+    }
+}
+
+/*
+ * Total-variation gradient (gridencoder.cu:506-601, bound to grid.py:176-198).  For every point and level: the cell corner
+ * pos_grid = floor(x * scale + 0.5); over the 2*D axis neighbours that exist (right when pos_grid[d] < resolution, left when
+ * pos_grid[d] > 0): results += g, idelta += g*g with g = table[corner] - table[neighbour]; then
+ * grad[corner] += (weight / (2*D)) * results * rsqrt(idelta + 1e-9).  inputs [B, D] f32 already in [0,1] (points outside are
+ * skipped); grad [sO, C] is accumulated into (the caller's embeddings.grad).  Sequential in b here, atomicAdd in arbitrary order
+ * in the reference: tolerance comparison only.  `g*g + idelta` is one FMA under nvcc's default contraction; rsqrtf is the
+ * reference's 2-ulp intrinsic, 1/sqrtf here.
+ */
+void nlr_oracle_grid_tv(const float *inputs, const float *table, float *grad, const int32_t *offsets, float weight, uint32_t B,
+                        uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners) {
+    float scale_l[32];
+    uint32_t res_l[32];
+    nlr_oracle_level_scale(L, S, H, scale_l, res_l);
+    const float w = weight / (float)(2 * D);
+    for (uint32_t level = 0; level < L; ++level) {
+        const float *tb = table + (size_t)(uint32_t)offsets[level] * C;
+        float *gg = grad + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        const float scale = scale_l[level];
+        const uint32_t resolution = res_l[level];
+        for (uint32_t b = 0; b < B; ++b) {
+            const float *x = inputs + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) continue;
+            uint32_t pos_grid[NLR_MAX_D];
+            for (uint32_t d = 0; d < D; d++) pos_grid[d] = (uint32_t)floorf(fmaf(x[d], scale, align_corners ? 0.0f : 0.5f));
+            float results[8] = {0}, idelta[8] = {0};
+            const uint32_t index = grid_index(gridtype, align_corners, D, C, hashmap_size, resolution, pos_grid);
+            for (uint32_t d = 0; d < D; d++) {
+                const uint32_t cur = pos_grid[d];
+                if (cur < resolution) {
+                    pos_grid[d] = cur + 1;
+                    const uint32_t ir = grid_index(gridtype, align_corners, D, C, hashmap_size, resolution, pos_grid);
+                    for (uint32_t ch = 0; ch < C; ch++) {
+                        const float g = tb[index + ch] - tb[ir + ch];
+                        results[ch] += g;
+                        idelta[ch] = fmaf(g, g, idelta[ch]);
+                    }
+                }
+                if (cur > 0) {
+                    pos_grid[d] = cur - 1;
+                    const uint32_t il = grid_index(gridtype, align_corners, D, C, hashmap_size, resolution, pos_grid);
+                    for (uint32_t ch = 0; ch < C; ch++) {
+                        const float g = tb[index + ch] - tb[il + ch];
+                        results[ch] += g;
+                        idelta[ch] = fmaf(g, g, idelta[ch]);
+                    }
+                }
+                pos_grid[d] = cur;
+            }
+            for (uint32_t ch = 0; ch < C; ch++) gg[index + ch] += (w * results[ch]) * (1.0f / sqrtf(idelta[ch] + 1e-9f));
         }
     }
 }

@@ -41,6 +41,7 @@ def _load_c():
         lib.nlr_oracle_grid_forward.restype = None
         lib.nlr_oracle_grid_backward.restype = None
         lib.nlr_oracle_level_scale.restype = None
+        lib.nlr_oracle_grid_tv.restype = None
         _LIB = lib
     return _LIB
 
@@ -99,6 +100,22 @@ def grid_backward_c(grad: np.ndarray, x01: np.ndarray, offsets: np.ndarray, n_en
         gi.ctypes.data_as(ctypes.c_void_p) if gi is not None else ctypes.c_void_p(0),
         ctypes.c_uint32(gridtype), ctypes.c_int(int(align_corners)), ctypes.c_uint32(interp))
     return gt, gi
+
+
+def grid_tv_c(x01: np.ndarray, table: np.ndarray, grad: np.ndarray, offsets: np.ndarray, weight: float, S: float, H: int,
+              gridtype: int = 0, align_corners: bool = False) -> np.ndarray:
+    """grad_total_variation (cu:506-601): returns grad + the TV gradient at the cells of x01 [B,D] (in [0,1])."""
+    lib = _load_c()
+    x01 = np.ascontiguousarray(x01, np.float32)
+    table = np.ascontiguousarray(table, np.float32)
+    out = np.array(grad, np.float32, copy=True, order="C")
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    B, D = x01.shape
+    lib.nlr_oracle_grid_tv(x01.ctypes.data_as(ctypes.c_void_p), table.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+                           offsets.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(weight), ctypes.c_uint32(B), ctypes.c_uint32(D),
+                           ctypes.c_uint32(table.shape[1]), ctypes.c_uint32(offsets.shape[0] - 1), ctypes.c_float(S), ctypes.c_uint32(H),
+                           ctypes.c_uint32(gridtype), ctypes.c_int(int(align_corners)))
+    return out
 
 
 def grid_encode_numpy(x01, table, offsets, S, H, gridtype=0, align_corners=False):

@@ -102,6 +102,50 @@ def test_gridencoder_module_and_backward():
                                      None, 0, False, 0)
 
 
+@pytest.mark.parametrize("which,log2_hashmap", [("nerf", 14), ("prop1", 12), ("prop0", 21)])
+def test_grad_total_variation_matches_oracle(which, log2_hashmap):
+    """`nlr_grad_total_variation` (gridencoder.h:15, cu:506-645) against the C restatement, through the C ABI and through
+    `GridEncoder.grad_total_variation` (grid.py:176-198)."""
+    mc = nconfig.workload("REF", log2_hashmap)
+    cfg = {"nerf": mc.nerf_mlp, "prop0": mc.prop_cfg(0), "prop1": mc.prop_cfg(1)}[which]
+    offsets, sizes, pls = nweights.grid_layout(cfg)
+    from nerflidar_hip import synth
+    Cc = cfg.grid_level_dim
+    table = synth.table_init(9, "tv" + which, int(offsets[-1]), Cc, 1.0)
+    x = _points(20000, 3)
+    S, H = float(np.log2(pls)), cfg.grid_base_resolution
+    g0 = (np.random.default_rng(2).standard_normal(table.shape) * 1e-3).astype(np.float32)
+    ref = orc.grid_tv_c(x, table, g0, offsets, 1e-2, S, H)
+    off = np.ascontiguousarray(offsets, np.int32)
+    xd, td, gd = cu(x), cu(table), cu(g0)
+    _lib.check(_lib.lib().nlr_grad_total_variation(_lib.ptr(xd), _lib.ptr(td), _lib.ptr(gd), off.ctypes.data, 1e-2, len(x), 3, Cc,
+                                                   len(offsets) - 1, S, H, 0, 0, None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(npy(gd), ref, rtol=2e-4, atol=2e-6)   # float atomics + v_rsq_f32 for 1/sqrt
+    assert np.abs(ref - g0).max() > 1e-3
+    rc = _lib.lib().nlr_grad_total_variation(_lib.ptr(xd), _lib.ptr(td), _lib.ptr(gd), off.ctypes.data, 1e-2, len(x), 2, Cc,
+                                             len(offsets) - 1, S, H, 0, 0, None)
+    assert rc == -1 and b"D = 3" in _lib.lib().nlr_last_error()
+
+
+def test_gridencoder_total_variation_method():
+    from nerflidar_hip.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=6, level_dim=2, base_resolution=16, desired_resolution=512, log2_hashmap_size=14,
+                      init_std=0.5).to(DEV)
+    with pytest.raises(ValueError, match="grad is None"):
+        enc.grad_total_variation(1e-3)
+    pts = cu(_points(4000, 4) * 2 - 1)
+    enc(pts).sum().backward()
+    g0 = npy(enc.embeddings.grad).copy()
+    enc.grad_total_variation(1e-3, inputs=pts, bound=1)
+    x01 = ((npy(pts) + 1) / 2).astype(np.float32)
+    ref = orc.grid_tv_c(x01, npy(enc.embeddings), g0, npy(enc.offsets), 1e-3, float(np.log2(enc.per_level_scale)), enc.base_resolution)
+    np.testing.assert_allclose(npy(enc.embeddings.grad), ref, rtol=2e-4, atol=2e-6)
+    enc.grad_total_variation(1e-3, B=1000)   # random cells (grid.py:188-190): runs, changes the gradient, stays finite
+    g2 = npy(enc.embeddings.grad)
+    assert np.isfinite(g2).all() and (g2 != ref).any()
+
+
 # ------------------------------------------------------------------------------------------------
 # a-2 / a-3 / a-4 resampling
 # ------------------------------------------------------------------------------------------------

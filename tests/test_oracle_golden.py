@@ -154,6 +154,54 @@ def test_grid_numpy_twin_matches_c():
         assert enc.offsets[-1] == sd[f"{prefix}.encoder.embeddings"].shape[0]
 
 
+def test_grid_tv_oracle_matches_numpy_restatement():
+    """kernel_grad_tv (gridencoder.cu:506-601) as the C checker states it against an independently written float64 numpy
+    version: dense and hashed levels, cells on the level boundary (a missing left / right neighbour), out-of-range points."""
+    from nerflidar_hip import synth
+    cfg = nconfig.workload("REF", 12).prop_cfg(1)
+    offsets, sizes, pls = nweights.grid_layout(cfg)
+    S, H, Cc = float(np.log2(pls)), cfg.grid_base_resolution, cfg.grid_level_dim
+    table = synth.table_init(7, "tv", int(offsets[-1]), Cc, 1.0)
+    rng = np.random.default_rng(1)
+    x = rng.random((3000, 3)).astype(np.float32)
+    x[:4] = np.array([[0, 0, 0], [1, 1, 1], [0, 1, 0.5], [1.0001, 0.5, 0.5]], np.float32)
+    g0 = rng.standard_normal(table.shape).astype(np.float32) * 1e-3
+    got = orc.grid_tv_c(x, table, g0, offsets, 1e-2, S, H)
+    scale, res = orc.level_scale(len(offsets) - 1, S, H)
+    want = g0.astype(np.float64)
+    primes = np.array([1, 2654435761, 805459861], np.uint64)
+    for lvl in range(len(offsets) - 1):
+        hs, r, step = int(offsets[lvl + 1] - offsets[lvl]), int(res[lvl]), int(res[lvl]) + 1
+        dense = step ** 3 <= hs
+        def index(p):
+            if dense:
+                return int(p[0] + p[1] * step + p[2] * step * step) % hs
+            h = np.uint64(0)
+            for d in range(3):
+                h ^= (np.uint64(p[d]) * primes[d]) & np.uint64(0xFFFFFFFF)
+            return int(h) % hs
+        # (gridencoder.cu:66-84: a level whose stride walk exceeds the table hashes the full coordinate, else x + y s + z s^2)
+        tb = table[offsets[lvl]:offsets[lvl + 1]].astype(np.float64)
+        for b in range(len(x)):
+            if ((x[b] < 0) | (x[b] > 1)).any():
+                continue
+            # x * scale + 0.5 as one float32 FMA (nvcc's contraction): exact in float64, rounded once
+            pg = np.floor((x[b].astype(np.float64) * float(scale[lvl]) + 0.5).astype(np.float32)).astype(np.int64)
+            i0 = index(pg)
+            resu, idel = np.zeros(Cc), np.zeros(Cc)
+            for d in range(3):
+                for sgn, ok in ((1, pg[d] < r), (-1, pg[d] > 0)):
+                    if ok:
+                        q = pg.copy()
+                        q[d] += sgn
+                        gval = tb[i0] - tb[index(q)]
+                        resu += gval
+                        idel += gval * gval
+            want[offsets[lvl] + i0] += (1e-2 / 6) * resu / np.sqrt(idel + 1e-9)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6)
+    assert np.abs(got - g0).max() > 1e-3  # the op did something
+
+
 def test_grid_layout_full_size():
     """Table footprints quoted in SURVEY a-7 (229 MiB NerfMLP etc.)."""
     mc = nconfig.workload("REF")
