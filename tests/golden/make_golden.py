@@ -554,9 +554,76 @@ def gen_checkpoint():
         print(f"  wrote ckpt_ref/{os.path.basename(path)}  ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def gen_losses():
+    """Row f-3: the loss terms train.py:326-446 sums, evaluated by the reference's own train_utils / stepfun / math on seeded ray
+    histories, with their gradients (autograd on the reference's code) w.r.t. what the optimiser can reach: the proposal weights
+    (interlevel terms), the final weights (distortion) and the rendered colours (data term)."""
+    print("loss fixtures")
+    for name in ("rawpy", "mediapy", "imageio", "tensorboardX", "plyfile", "trimesh", "nuscenes"):  # IO packages of datasets.py
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                _stub(name)
+    _stub("pycolmap", SceneManager=object)
+    for _ in range(20):
+        try:
+            from internal import train_utils as rtu, configs as rcfg
+            break
+        except ModuleNotFoundError as e:
+            _stub(e.name)
+    cfg = rcfg.Config()
+    cfg.interlevel_loss_mult = 1.0      # (0 in the shipped gin: exercised here all the same)
+    N, samples = 48, (64, 64, 32)
+    hist = []
+    for li, S in enumerate(samples):
+        inner = torch.sort(rnd(70, li, (N, S - 1), 0.0, 1.0), dim=-1)[0]
+        if li == 2:  # the final level concentrates where the weights are
+            inner = torch.sort(0.3 + 0.4 * rnd(70, 10 + li, (N, S - 1), 0.0, 1.0) ** 2, dim=-1)[0]
+        sd = torch.cat([torch.zeros(N, 1), inner, torch.ones(N, 1)], dim=-1)
+        sd[5, 7] = sd[5, 6]  # a zero-width interval
+        w = torch.softmax(rnd(70, 20 + li, (N, S), -4, 4), dim=-1) * rnd(70, 30 + li, (N, 1), 0.5, 1.0)
+        hist.append(dict(sdist=sd, weights=w.clone().requires_grad_(True)))
+    out = dict(pulse_width=np.asarray(cfg.pulse_width, np.float32), charb_padding=np.float32(cfg.charb_padding),
+               anti_mult=np.float32(cfg.anti_interlevel_loss_mult), dist_mult=np.float32(cfg.distortion_loss_mult),
+               inter_mult=np.float32(cfg.interlevel_loss_mult))
+    for li, h in enumerate(hist):
+        out[f"sdist{li}"], out[f"weights{li}"] = h["sdist"], h["weights"].detach()
+    for tag, fn in (("anti", rtu.anti_interlevel_loss), ("inter", rtu.interlevel_loss), ("dist", rtu.distortion_loss)):
+        loss = fn(hist, cfg)
+        grads = torch.autograd.grad(loss, [h["weights"] for h in hist], allow_unused=True)
+        out[f"{tag}_loss"] = loss.detach()
+        for li, g in enumerate(grads):
+            out[f"{tag}_g{li}"] = torch.zeros_like(hist[li]["weights"]) if g is None else g
+    # with the dynamic-object mask (train_utils.py:153-154)
+    mask = rnd(70, 50, (N, samples[0])) > 0.8
+    hist_m = [dict(h) for h in hist]
+    hist_m[0]["obj_mask"] = mask
+    hist_m[1]["obj_mask"] = rnd(70, 51, (N, samples[1])) > 0.9
+    loss = rtu.anti_interlevel_loss(hist_m, cfg)
+    g = torch.autograd.grad(loss, [hist[0]["weights"], hist[1]["weights"]])
+    out.update(obj_mask0=hist_m[0]["obj_mask"], obj_mask1=hist_m[1]["obj_mask"], anti_masked_loss=loss.detach(), anti_masked_g0=g[0], anti_masked_g1=g[1])
+    # data term (train_utils.py:55-117), charbonnier and mse, with a ray mask
+    rgbs = [rnd(71, li, (N, 3)).requires_grad_(True) for li in range(3)]
+    batch = dict(rgb=rnd(71, 10, (N, 3)), mask_rgb=(rnd(71, 11, (N,)) > 0.3))
+    for kind in ("charb", "mse"):
+        cfg.data_loss_type = kind
+        cfg.data_coarse_loss_mult = 0.5
+        loss, _ = rtu.compute_data_loss(batch, [dict(rgb=r) for r in rgbs], cfg)
+        g = torch.autograd.grad(loss, rgbs)
+        out[f"data_{kind}_loss"] = loss.detach()
+        for li in range(3):
+            out[f"data_{kind}_g{li}"] = g[li]
+    out.update(data_rgb=batch["rgb"], data_mask=batch["mask_rgb"], data_coarse_mult=np.float32(0.5), **{f"data_pred{li}": r.detach() for li, r in enumerate(rgbs)})
+    save("fn_losses", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if os.environ.get("NLR_GOLDEN_ONLY") == "losses":
+        gen_losses()
+        raise SystemExit(0)
     if os.environ.get("NLR_GOLDEN_ONLY") == "f4":
         gen_raydrop_apply()
         gen_checkpoint()
@@ -575,4 +642,5 @@ if __name__ == "__main__":
     gen_composite_grad()
     gen_raydrop_apply()
     gen_checkpoint()
+    gen_losses()
     print("done")
