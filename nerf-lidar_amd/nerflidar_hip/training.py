@@ -1,9 +1,11 @@
-"""Training-side operators on the fused path (scope row f-3): differentiable compositing and the hash-decay loss.
+"""Training on the fused path (scope row f-3): the operators with HIP backward kernels and the modules that chain them.
 
-With `gridencoder.GridEncoder` (HIP forward + backward, Z/gridencoder/grid.py:24-89) these are the ends of the training
-graph of ZI/train.py:272-281,459: hash-grid features in, composited ray outputs and the regulariser out.  The MLP between
-them is `torch.nn.functional.linear` on the GPU here (the fused MFMA kernel is inference-only; its backward is the open
-part of row f-3), and proposal resampling carries no gradient in the reference either (`Model.stop_level_grad`).
+  * differentiable compositing (`nlr_composite_level` / `nlr_composite_backward`) and the hash-decay regulariser;
+  * `gridencoder.GridEncoder` (HIP forward + backward + total-variation gradient, Z/gridencoder/grid.py:24-198);
+  * the NerfMLP either as torch Linear modules or through the fused MFMA forward / backward (`_FusedMLP`);
+  * `TrainableNerfLevel`, `TrainablePropLevel`, `TrainableModel`: the reference's `Model.forward` with autograd (proposal
+    resampling carries no gradient in the reference either, `Model.stop_level_grad`), and `training_step`: the step of
+    ZI/train.py:272-459 with the loss dictionary of `nerflidar_hip.losses`.
 """
 from __future__ import annotations
 
@@ -127,7 +129,8 @@ def hash_decay_loss(encoders, mult: float = 1.0) -> torch.Tensor:
 
 
 # ---- a trainable NerfMLP level: fused cast/contract + HIP grid op (fwd/bwd) + torch Linear stack + HIP compositing (fwd/bwd) ----------
-def cast_contract(batch: Dict[str, torch.Tensor], tdist: torch.Tensor, sample_n: int = 7, sample_m: int = 3, std_scale: float = 0.35):
+def cast_contract(batch: Dict[str, torch.Tensor], tdist: torch.Tensor, sample_n: int = 7, sample_m: int = 3, std_scale: float = 0.35,
+                  rand_deg: Optional[torch.Tensor] = None):
     """Rows a-5 + a-6 (`nlr_cast_contract`): multisample means / bound [N,S,n,3] and stds / bound [N,S,n] of the intervals of
     `tdist`, as MLP.predict_density feeds them to the encoder (ZI/models.py:965-973).  Carries no gradient (tdist is detached in
     training, Model.stop_level_grad)."""
@@ -145,7 +148,8 @@ def cast_contract(batch: Dict[str, torch.Tensor], tdist: torch.Tensor, sample_n:
     means = torch.empty(n, S, sample_n, 3, device=dev)
     stds = torch.empty(n, S, sample_n, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().nlr_cast_contract(C.byref(rays), _lib.ptr(td), n, S, sample_n, sample_m, float(std_scale), None, _lib.ptr(means),
+        rd = None if rand_deg is None else rand_deg.reshape(n, S, sample_n).contiguous().float()   # U[0,1) draws, render.py:150
+        rc = _lib.lib().nlr_cast_contract(C.byref(rays), _lib.ptr(td), n, S, sample_n, sample_m, float(std_scale), _lib.ptr(rd), _lib.ptr(means),
                                           _lib.ptr(stds), _lib.current_stream())
     _lib.check(rc, "nlr_cast_contract")
     return means, stds
@@ -325,11 +329,12 @@ class TrainableNerfLevel(torch.nn.Module):
             raise KeyError(f"state_dict mismatch: missing {bad}, unexpected {list(unexpected)}")
         return self
 
-    def forward(self, batch: Dict[str, torch.Tensor], tdist: torch.Tensor, sample_n: int = 7, sample_m: int = 3) -> Dict[str, torch.Tensor]:
+    def forward(self, batch: Dict[str, torch.Tensor], tdist: torch.Tensor, sample_n: int = 7, sample_m: int = 3,
+                rand_deg: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         from .objects import _pos_enc
         F = torch.nn.functional
         cfg = self.cfg
-        means, stds = cast_contract(batch, tdist, sample_n, sample_m)
+        means, stds = cast_contract(batch, tdist, sample_n, sample_m, rand_deg=rand_deg)
         if self.fused_mlp:
             return self._forward_fused(batch, encode_features(self.encoder, means, stds, cfg.re_weights))
         x = self.density_layer(encode_features(self.encoder, means, stds, cfg.re_weights))
@@ -387,3 +392,125 @@ class TrainableNerfLevel(torch.nn.Module):
         r = volumetric_render(o["density"], tdist, batch["directions"].reshape(tdist.shape[0], 3), o["rgb"], o.get("semantic"),
                               o.get("intensity"), opaque_background, bg)
         return r, o
+
+
+# ---- the whole model for training: Model.forward (ZI/models.py:239-576) with autograd, and the step of train.py:272-459 -------------
+class TrainablePropLevel(torch.nn.Module):
+    """A PropMLP (ZI/models.py:PropMLP: disable_rgb) with the reference's parameter names: `encoder.embeddings`,
+    `density_layer.{0,2}.{weight,bias}`."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        from .gridencoder import GridEncoder
+        nn = torch.nn
+        self.cfg = cfg
+        self.encoder = GridEncoder(input_dim=3, num_levels=cfg.grid_num_levels, level_dim=cfg.grid_level_dim,
+                                   base_resolution=cfg.grid_base_resolution, desired_resolution=cfg.grid_disired_resolution,
+                                   log2_hashmap_size=cfg.grid_log2_hashmap_size, gridtype="hash", align_corners=False)
+        self.density_layer = nn.Sequential(nn.Linear(cfg.grid_num_levels * cfg.grid_level_dim, 64), nn.ReLU(), nn.Linear(64, 1))
+
+    load_reference = TrainableNerfLevel.load_reference
+
+    def forward(self, batch, tdist, sample_n: int = 7, sample_m: int = 3, rand_deg=None) -> Dict[str, torch.Tensor]:
+        means, stds = cast_contract(batch, tdist, sample_n, sample_m, rand_deg=rand_deg)
+        x = self.density_layer(encode_features(self.encoder, means, stds, self.cfg.re_weights))
+        return {"density": torch.nn.functional.softplus(x[..., 0] + self.cfg.density_bias)}
+
+
+class TrainableModel(torch.nn.Module):
+    """`Model` (ZI/models.py:31-576, instance_obj = False, no GLO) as a trainable module: submodules `prop_mlp_<i>` and
+    `nerf_mlp` with the reference's parameter names, so a reference checkpoint loads with `load_reference` and the trained
+    `state_dict()` goes straight into `nerflidar_hip.models.Model` for fused inference.
+
+    forward = the level loop of models.py:316-557 in training form: the sample positions come from the fused resampling kernel
+    (`nlr_resample_level`; they carry no gradient, Model.stop_level_grad = True), cast / contraction from `nlr_cast_contract`,
+    hash-grid features and their gradient from the HIP grid operator, the NerfMLP from torch Linear modules or the fused MFMA
+    forward / backward (`fused_mlp=True`), compositing and its gradient from `nlr_composite_level` / `nlr_composite_backward`."""
+
+    def __init__(self, mc, fused_mlp: bool = False):
+        super().__init__()
+        self.mc = mc
+        for i in range(mc.num_levels - 1):
+            self.add_module(f"prop_mlp_{i}", TrainablePropLevel(mc.prop_cfg(i)))
+        import dataclasses
+        ncfg = dataclasses.replace(mc.nerf_mlp, use_semantic=mc.config.use_semantic, use_intensity=mc.config.use_intensity,
+                                   no_sem_layer=mc.config.no_sem_layer)
+        self.nerf_mlp = TrainableNerfLevel(ncfg, fused_mlp=fused_mlp)
+
+    def levels(self):
+        return [getattr(self, f"prop_mlp_{i}") for i in range(self.mc.num_levels - 1)] + [self.nerf_mlp]
+
+    def load_reference(self, state_dict):
+        for i in range(self.mc.num_levels - 1):
+            getattr(self, f"prop_mlp_{i}").load_reference(state_dict, f"prop_mlp_{i}.")
+        self.nerf_mlp.load_reference(state_dict, "nerf_mlp.")
+        return self
+
+    def reference_state_dict(self) -> Dict[str, np.ndarray]:
+        """Parameters under the reference's names (what `Model(mc, sd)` and `checkpoints.save_checkpoint` take)."""
+        return {k: v.detach().cpu().numpy() for k, v in self.state_dict().items() if not k.endswith(("encoder.offsets", "encoder.grid_sizes", "encoder.idx"))}
+
+    def forward(self, batch: Dict[str, torch.Tensor], train_frac: float = 1.0, rand: Optional[torch.Generator] = None, randomized: bool = False,
+                sample_n: int = 7, sample_m: int = 3):
+        """-> (renderings, ray_history), one entry per level, like `Model.forward`.  randomized (or a generator in `rand`): per-ray
+        jitter of the sample positions (stepfun.py:216) and per-multisample rotation (render.py:150), as `model(True, ...)` draws
+        them in train.py:272."""
+        mc = self.mc
+        L = _lib.lib()
+        n = batch["origins"].shape[0]
+        dev = batch["origins"].device
+        near, far = batch["near"].reshape(n).contiguous().float(), batch["far"].reshape(n).contiguous().float()
+        dirs = batch["directions"].reshape(n, 3).contiguous().float()
+        randomized = randomized or rand is not None
+        prev_s = prev_w = None
+        n_prev, prod = 0, 1.0
+        renderings, history = [], []
+        samples = mc.level_samples()
+        for li, (S, level) in enumerate(zip(samples, self.levels())):
+            last = li == len(samples) - 1
+            use_dil = mc.dilation_bias > 0 or mc.dilation_multiplier > 0                      # models.py:322-346
+            dilation = (mc.dilation_bias + mc.dilation_multiplier * 1.0 / prod) if (li > 0 and use_dil) else 0.0
+            prod *= S
+            anneal = (mc.anneal_slope * train_frac) / ((mc.anneal_slope - 1) * train_frac + 1) if mc.anneal_slope > 0 else 1.0
+            sdist, tdist = torch.empty(n, S + 1, device=dev), torch.empty(n, S + 1, device=dev)
+            jit = torch.rand(n, device=dev, generator=rand) if randomized else None
+            with torch.cuda.device(dev):
+                _lib.check(L.nlr_resample_level(_lib.ptr(prev_s), _lib.ptr(prev_w), n_prev, float(dilation), float(anneal), float(mc.resample_padding), S,
+                                                _lib.ptr(jit), _lib.ptr(near), _lib.ptr(far), float(mc.power_lambda), n, _lib.ptr(sdist), _lib.ptr(tdist),
+                                                _lib.current_stream()), "nlr_resample_level")
+            rd = torch.rand(n, S, sample_n, device=dev, generator=rand) if randomized else None
+            o = level(batch, tdist, sample_n, sample_m, rand_deg=rd)
+            rgbs = o["rgb"] if last else torch.zeros(n, S, 3, device=dev)   # a PropMLP renders black (models.py:1119-1122)
+            r = volumetric_render(o["density"], tdist, dirs, rgbs, o.get("semantic") if last else None, o.get("intensity") if last else None,
+                                  bool(mc.opaque_background), mc.bg_intensity_range[0] if mc.bg_intensity_range[0] == mc.bg_intensity_range[1]
+                                  else sum(mc.bg_intensity_range) / 2)
+            weights = r.pop("weights")
+            renderings.append(r)
+            history.append(dict(sdist=sdist, tdist=tdist, weights=weights, density=o["density"]))
+            prev_s, prev_w, n_prev = sdist, weights.detach().contiguous(), S
+        return renderings, history
+
+
+def training_step(model: TrainableModel, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], train_frac: float = 1.0,
+                  randomized: bool = True, hash_decay_mult: float = 0.1, tv_weight: float = 0.0, grad_max_norm: float = 0.0,
+                  **loss_kw) -> Dict[str, float]:
+    """One optimiser step as train.py:272-459 takes it: forward with random jitter, the loss dictionary (`losses.total_loss` +
+    hash decay), backward through the HIP backward kernels, optional total-variation gradient on the tables (grid.py:176-198),
+    gradient clipping (train_utils.clip_gradients), step.  Returns the loss terms as floats."""
+    from . import losses as nlosses
+    optimizer.zero_grad(set_to_none=True)
+    renderings, history = model(batch, train_frac=train_frac, randomized=randomized)
+    terms = nlosses.total_loss(renderings, history, batch, **loss_kw)
+    if hash_decay_mult > 0:
+        terms["hash_decay"] = hash_decay_loss([lv.encoder for lv in model.levels()], hash_decay_mult)
+    loss = sum(terms.values())
+    loss.backward()
+    if tv_weight > 0:
+        for lv in model.levels():
+            lv.encoder.grad_total_variation(tv_weight)
+    if grad_max_norm > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), grad_max_norm)
+    optimizer.step()
+    out = {k: float(v.detach()) for k, v in terms.items()}
+    out["loss"] = float(loss.detach())
+    return out

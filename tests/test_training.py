@@ -6,6 +6,7 @@ import torch
 
 from conftest import GOLDEN, golden
 from oracle import nlr_oracle as orc
+from nerflidar_hip import training as ntrain
 
 T = torch.from_numpy
 TAGS = ["opaque", "transparent"]
@@ -360,3 +361,82 @@ def test_fused_training_mlp_matches_torch_autograd(wl, S):
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
+
+
+# ---- the whole model: forward consistency with the fused inference path, and the training step of train.py:272-459 ------------------
+def _ref_scene(log2_hashmap=12, width=64, seed=0):
+    from nerflidar_hip import config as nconfig, lidar as nlidar, weights as nweights
+    mc = nconfig.workload("REF", log2_hashmap)
+    sd = nweights.synth_state_dict(mc, seed=seed, trained_like=True)
+    b = nlidar.synthetic_sweep(width=width, seed=seed)
+    return mc, sd, {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+
+
+@pytest.mark.gpu
+def test_trainable_model_computes_what_the_fused_inference_path_computes():
+    """`TrainableModel.forward` (autograd graph over the HIP operators) and `Model.forward` (the fused inference path, pinned on the
+    reference's fixtures) on the same weights and rays: same sample positions, same weights, same renderings."""
+    from nerflidar_hip.models import Model
+    mc, sd, batch = _ref_scene()
+    tm = ntrain.TrainableModel(mc).cuda().load_reference(sd)
+    with torch.no_grad():
+        rend, hist = tm(batch, train_frac=1.0)
+    ref_r, ref_h = Model(mc, sd, precision=0)(False, batch, train_frac=1.0, compute_extras=True)
+    for li in range(3):
+        # level 0 resamples the same [0, 1] interval: identical positions; later levels invert a CDF built from the previous
+        # level's weights, which differ by the summation order of the density MLP (torch GEMM here, fused kernel there)
+        # (where the previous level's CDF is flat a 1e-6 change of a weight moves a sample by 1e-4: a handful of positions)
+        ds = (hist[li]["sdist"] - ref_h[li]["sdist"]).abs()
+        if li == 0:
+            assert float(ds.max()) == 0.0
+        else:
+            assert float(ds.mean()) <= 1e-6 and float((ds > 1e-4).float().mean()) <= 1e-3 and float(ds.max()) <= 5e-3, (li, float(ds.mean()), float(ds.max()))
+        dw = (hist[li]["weights"] - ref_h[li]["weights"]).abs()
+        # (a surface sample that moved takes its weight along: rare, large, and invisible in the composited outputs below)
+        assert float(dw.mean()) <= 2e-5 and float((dw > 1e-3).float().mean()) <= 1e-3, (li, float(dw.mean()), float(dw.max()))
+        assert float((rend[li]["depth"] - ref_r[li]["depth"]).abs().mean()) <= 1e-4
+    for k in ("rgb", "depth", "semantic", "acc"):   # the two paths agree to summation-order noise, amplified on a few edge rays
+        d = (rend[-1][k] - ref_r[-1][k]).abs()
+        assert float(d.mean()) <= 2e-4 and float((d > 1e-3).float().mean()) <= 2e-2 and float(d.max()) <= 1e-1, (k, float(d.mean()), float(d.max()))
+    assert float((rend[-1]["semantic"].argmax(-1) == ref_r[-1]["semantic"].argmax(-1)).float().mean()) >= 0.995
+    # and the trained parameters go back into the inference path unchanged
+    back = tm.reference_state_dict()
+    for k, v in sd.items():
+        if not k.endswith(("encoder.offsets", "encoder.grid_sizes", "encoder.idx")):
+            np.testing.assert_array_equal(back[k], np.asarray(v, np.float32), err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_training_step_of_the_whole_model(fused):
+    """train.py:272-459 on the fused path: a student with the reference's init learns a teacher's sweep (colour, depth, labels);
+    every loss term is finite, the interlevel term reaches the proposal networks, hash tables of all three levels get gradients,
+    and the loss goes down."""
+    from nerflidar_hip.models import Model
+    from nerflidar_hip import weights as nweights
+    mc, sd, batch = _ref_scene(width=32)
+    with torch.no_grad():
+        teach = Model(mc, sd, precision=0).render_rays(batch)[0]
+    batch = dict(batch, rgb=teach["rgb"].clone(), depth=teach["depth"].clone(), semantic=teach["semantic"].argmax(-1))
+    torch.manual_seed(0)
+    tm = ntrain.TrainableModel(mc, fused_mlp=fused).cuda()
+    tm.load_reference(nweights.synth_state_dict(mc, seed=5, trained_like=True))   # a different scene: something to unlearn
+    opt = torch.optim.Adam(tm.parameters(), lr=2e-3, eps=1e-15)
+    kw = dict(depth_lam=0.4, sem_lam=0.04, interlevel_mult=0.0, anti_interlevel_mult=0.01, distortion_mult=0.005)
+    first = ntrain.training_step(tm, opt, batch, randomized=True, tv_weight=1e-7, grad_max_norm=1.0, **kw)
+    assert set(first) >= {"data", "depth", "sem", "interlevel", "distortion", "hash_decay", "loss"}
+    assert all(np.isfinite(v) for v in first.values()), first
+    # gradients of that first step reached every trainable part (checked on a fresh backward, the step cleared nothing)
+    for name in ("prop_mlp_0.density_layer.0.weight", "prop_mlp_1.encoder.embeddings", "nerf_mlp.encoder.embeddings",
+                 "nerf_mlp.lin_second_stage_1.weight", "nerf_mlp.sem_layer.2.weight"):
+        g = dict(tm.named_parameters())[name].grad
+        assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0, name
+    hist = [first["loss"]]
+    for _ in range(40):
+        hist.append(ntrain.training_step(tm, opt, batch, randomized=True, grad_max_norm=1.0, **kw)["loss"])
+    assert np.isfinite(hist).all()
+    assert np.mean(hist[-5:]) < 0.7 * np.mean(hist[:3]), (hist[:3], hist[-5:])
+    # the trained state dict renders through the fused inference path
+    m = Model(mc, tm.reference_state_dict(), precision=2)
+    r = m.render_rays(batch)[0]
+    assert bool(torch.isfinite(r["depth"]).all())
