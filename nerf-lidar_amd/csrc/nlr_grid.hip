@@ -261,24 +261,67 @@ __device__ __forceinline__ void nlr_agg_atomic(float *gt, uint32_t addr, float v
     }
 }
 
+// Run-length aggregation.  The points of a batch arrive in ray order (ray, sample, multisample): neighbouring lanes of a channel
+// are neighbouring points on one ray and, on every level coarser than their spacing, fall into the same cell - a wave would send
+// runs of atomics to one address, which the memory pipeline serialises.  A segmented inclusive scan over the runs of equal
+// address inside each 16-lane row (DPP row_shr; the kernel lays a wave out channel-major, so the stride is 1 and lanes of
+// different channels never share an address) leaves every run's sum in its last lane, and only that lane issues the atomic.  Correct for any address sequence: only contiguous equal addresses are merged.
+template <int CTRL>
+__device__ __forceinline__ uint32_t nlr_dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int C>
+__device__ __forceinline__ void nlr_run_atomic(float *gt, uint32_t addr, float v, bool valid, int lane) {
+    const int r = lane & 15;
+    const uint32_t key = valid ? addr : 0xffffffffu - (uint32_t)lane;  // invalid lanes never match a neighbour
+    if (!valid) v = 0.0f;
+    // head of a run: no lane C to the left in the row, or a different address there
+    constexpr int SHR = 0x110;  // row_shr:n = 0x110 + n
+    constexpr int SHL = 0x100;  // row_shl:n = 0x100 + n
+    const uint32_t left = nlr_dpp_u<SHR + C>(key);
+    uint32_t head = (r < C || left != key) ? 1u : 0u;
+    const uint32_t right_head = nlr_dpp_u<SHL + C>(head);
+    const bool tail = (r >= 16 - C) || right_head != 0u;
+#define NLR_RUN_STEP(D)                                          \
+    if constexpr ((D) < 16) {                                      \
+        const float vo = nlr_dpp_f<SHR + (D)>(v);                 \
+        const uint32_t ho = r < (D) ? 1u : nlr_dpp_u<SHR + (D)>(head); \
+        if (!head) {                                               \
+            v += vo;                                               \
+            head = ho;                                             \
+        }                                                          \
+    }
+    NLR_RUN_STEP(C)
+    NLR_RUN_STEP(2 * C)
+    NLR_RUN_STEP(4 * C)
+    NLR_RUN_STEP(8 * C)
+#undef NLR_RUN_STEP
+    if (valid && tail) atomicAdd(gt + addr, v);
+}
+
 // One lane per (point, channel): the C channel atomics of a corner go out in ONE instruction as C adjacent lanes on C
 // consecutive floats, so a 64-lane atomic touches 64/C table entries instead of 64 - the L2 atomic path is paid per
 // distinct line (the per-point form spent C instructions of 64 scattered lines each on the same bytes).
 template <int C>
 __global__ void __launch_bounds__(256) nlr_grid_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ x,
                                                            GridParams gp, float *__restrict__ grad_table, uint32_t B,
-                                                           int grad_layout) {
+                                                           int grad_layout, int lds_levels) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b0 = t / C, ch = t % C;
     const int lane = threadIdx.x & 63;
+    // channel-major inside the wave: a wave owns P = 64 / C consecutive points, lane = ch * P + point.  Neighbouring lanes are
+    // then neighbouring points of ONE channel (runs of equal address for the run aggregation below), and the C channels of a
+    // cell still leave in one instruction on C consecutive floats.
+    constexpr uint32_t P = 64 / C;
+    const uint32_t b0 = (t >> 6) * P + ((uint32_t)lane % P), ch = (uint32_t)lane / P;
     const uint32_t level = blockIdx.y;
+    if (lds_levels && gp.mode[level] == 0 && gp.hsize[level] * C <= 36864) return;  // accumulated in LDS by nlr_grid_bwd_lds_kernel
     const bool aggregate = gp.mode[level] == 0;  // dense level (wave-uniform)
     const bool inb = b0 < B;
-    if (!aggregate && !inb) return;
+    // (no early exit per lane: the run scan reads its neighbours through DPP, inactive lanes would read as zero keys)
     const uint32_t b = inb ? b0 : B - 1;
     const float x0 = x[(size_t)b * 3 + 0], x1 = x[(size_t)b * 3 + 1], x2 = x[(size_t)b * 3 + 2];
     const bool valid = inb && !((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
-    if (!aggregate && !valid) return;
+    if (__ballot(valid) == 0ull) return;  // wave-uniform
     const float gc = grad_layout == 0 ? grad[((size_t)level * B + b) * C + ch] : grad[(size_t)b * gp.L * C + level * C + ch];
     float *gt = grad_table + (size_t)gp.offset[level] * C;
     const uint32_t hsize = gp.hsize[level], res = gp.res[level];
@@ -308,8 +351,68 @@ __global__ void __launch_bounds__(256) nlr_grid_bwd_kernel(const float *__restri
             }
         }
         const uint32_t addr = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pl[0], pl[1], pl[2]) * C + ch;
-        if (aggregate) nlr_agg_atomic(gt, addr, ww * gc, valid, lane);
+        if (C <= 8) nlr_run_atomic<1>(gt, addr, ww * gc, valid, lane);
+        else if (aggregate) nlr_agg_atomic(gt, addr, ww * gc, valid, lane);
         else atomicAdd(gt + addr, ww * gc);
+    }
+}
+
+// Dense coarse levels whose whole table fits in LDS (17^3 x C <= 4, 33^3 x 1): every sample of a batch lands in the same few
+// thousand cells, and their global atomics serialise on those addresses (level 0 of the C = 4 grid cost 3.0 of the 8.6 ms of a
+// 1.8 M-point backward).  Here a workgroup accumulates its share of the points in an LDS copy of the level (ds_add_f32) and adds
+// the copy to the table once: global atomics per level = cells x workgroups instead of points x 8 corners.
+#define NLR_LDS_TABLE_FLOATS 36864  // 144 KiB
+__host__ __device__ __forceinline__ bool nlr_level_fits_lds(const GridParams &gp, uint32_t level, uint32_t C) {
+    return gp.mode[level] == 0 && gp.hsize[level] * C <= NLR_LDS_TABLE_FLOATS;
+}
+template <int C>
+__global__ void __launch_bounds__(1024) nlr_grid_bwd_lds_kernel(const float *__restrict__ grad, const float *__restrict__ x, GridParams gp,
+                                                               float *__restrict__ grad_table, uint32_t B, int grad_layout) {
+    __shared__ float acc[NLR_LDS_TABLE_FLOATS];
+    const uint32_t level = blockIdx.y;
+    if (!nlr_level_fits_lds(gp, level, C)) return;  // (wave-uniform: the whole workgroup)
+    const uint32_t cells = gp.hsize[level] * C;
+    for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t hsize = gp.hsize[level], res = gp.res[level];
+    const float scale = gp.scale[level];
+    const float half = gp.align_corners ? 0.0f : 0.5f;
+    const uint32_t total = B * C;  // one lane per (point, channel), workgroups stride over the batch
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const uint32_t b = t / C, ch = t % C;
+        const float x0 = x[(size_t)b * 3 + 0], x1 = x[(size_t)b * 3 + 1], x2 = x[(size_t)b * 3 + 2];
+        if ((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1)) continue;
+        const float gc = grad_layout == 0 ? grad[((size_t)level * B + b) * C + ch] : grad[(size_t)b * gp.L * C + level * C + ch];
+        float pos[3] = {fmaf(x0, scale, half), fmaf(x1, scale, half), fmaf(x2, scale, half)};
+        uint32_t pg[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            pg[d] = (uint32_t)floorf(pos[d]);
+            pos[d] -= (float)pg[d];
+            if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+        }
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            float ww = 1.0f;
+            uint32_t pl[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if ((c8 >> d) & 1) {
+                    ww *= pos[d];
+                    pl[d] = pg[d] + 1;
+                } else {
+                    ww *= 1 - pos[d];
+                    pl[d] = pg[d];
+                }
+            }
+            atomicAdd(&acc[nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pl[0], pl[1], pl[2]) * C + ch], ww * gc);
+        }
+    }
+    __syncthreads();
+    float *gt = grad_table + (size_t)gp.offset[level] * C;
+    for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) {
+        const float v = acc[i];
+        if (v != 0.0f) atomicAdd(gt + i, v);
     }
 }
 
@@ -342,11 +445,26 @@ extern "C" int nlr_grid_encode_backward(const float *grad, const float *inputs, 
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(((size_t)B * C + 255) / 256), L), block(256);  // one lane per (point, channel)
+    // levels small enough for an LDS copy go through nlr_grid_bwd_lds_kernel when the batch is large enough to pay for the flush
+    bool any_lds = false;
+    for (uint32_t l = 0; l < L; ++l) any_lds = any_lds || nlr_level_fits_lds(gp, l, C);
+    const int lds_levels = (any_lds && (size_t)B * C >= (1u << 18)) ? 1 : 0;
+    if (lds_levels) {
+        const uint32_t nb = (uint32_t)std::min<size_t>(256, ((size_t)B * C + 16383) / 16384);  // >= 16 K lanes of work per workgroup, one per CU
+        dim3 g2(nb, L), b2(1024);
+        switch (C) {
+            case 1: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<1>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
+            case 2: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<2>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
+            case 4: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<4>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
+            default: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<8>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
+        }
+        NLR_LAUNCH_CHECK("nlr_grid_bwd_lds_kernel");
+    }
     switch (C) {
-        case 1: hipLaunchKernelGGL(nlr_grid_bwd_kernel<1>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
-        case 2: hipLaunchKernelGGL(nlr_grid_bwd_kernel<2>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
-        case 4: hipLaunchKernelGGL(nlr_grid_bwd_kernel<4>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
-        default: hipLaunchKernelGGL(nlr_grid_bwd_kernel<8>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
+        case 1: hipLaunchKernelGGL(nlr_grid_bwd_kernel<1>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
+        case 2: hipLaunchKernelGGL(nlr_grid_bwd_kernel<2>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
+        case 4: hipLaunchKernelGGL(nlr_grid_bwd_kernel<4>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
+        default: hipLaunchKernelGGL(nlr_grid_bwd_kernel<8>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
     }
     NLR_LAUNCH_CHECK("nlr_grid_bwd_kernel");
     if (dy_dx) {
