@@ -26,3 +26,6 @@ print("blocks with sane stamps:", int(ok.sum()), " in-kernel clock (MHz, median)
 med = np.median(d[ok], axis=0)
 for n, v in zip(names, med): print(f"  {n:28s} {v:10.0f} cycles ({100 * v / med.sum():5.1f} %)")
 print(f"  total per 256-sample tile     {med.sum():10.0f} cycles")
+tot = d[ok].sum(1); us = tot / clk[ok]
+q = lambda a: " / ".join(f"{v:.1f}" for v in np.percentile(a, [0, 5, 50, 95, 100]))
+print(f"  per-workgroup spread (min / p5 / median / p95 / max): cycles per tile {q(tot / 1e3)} k, clock {q(clk[ok])} MHz, time per tile {q(us)} us")
