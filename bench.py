@@ -48,6 +48,8 @@ def parse_args(argv=None):
     ap.add_argument("--table-dtype", choices=["f32", "f16"], default="f32", help="hash-table storage; f32 is the benchmark "
                     "configuration, f16 is what the reference uses under autocast (Z/gridencoder/grid.py:43-44)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: self-launch, initialise RCCL and run the collective also with one rank")
+    ap.add_argument("--emulate-world", type=int, default=0, help="diagnostic, one GPU: time the step one rank of a P-way azimuth split "
+                    "runs (sector 0 of P, no collective); the JSON line says so and is not a benchmark result")
     ap.add_argument("--chunk", type=int, default=0, help="rays per nlr_render_rays call (0 = the whole sector at once)")
     ap.add_argument("--history", action="store_true", help="also write the per-sample heads of the last level (ray_history)")
     ap.add_argument("--selftest-cpu", action="store_true", help="launcher + partition + collective logic on CPU (gloo) with a "
@@ -190,10 +192,13 @@ def main():
                   table_dtype=torch.float16 if args.table_dtype == "f16" else torch.float32)
     width = W_COLS * (world if args.scaling == "weak" else 1)
     full = nlidar.synthetic_sweep(width=width, seed=0)
-    sec, wp = nlidar.azimuth_sector(full, H_BEAMS, width, rank, world)
+    emul = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
+    sec, wp = nlidar.azimuth_sector(full, H_BEAMS, width, rank, emul or world)
     batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in sec.items()}
     n_rays = H_BEAMS * wp
     sf = 1.0 / 250.0
+    if emul:
+        width = wp  # the "image" of the emulation is the rank's own tile
     gat = sharding.SweepGatherer(H_BEAMS, width, dev, force=args.force_dist)
     last = {}
 
@@ -300,6 +305,11 @@ def main():
                          "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote},
             "kernel_source_sha": src[:16],
         }
+        if emul:  # not a benchmark result: what ONE rank of an `emul`-way split does per step, measured on one GPU
+            out["emulated_world"] = emul
+            out["metric"] = f"DIAGNOSTIC per-rank step of a {emul}-way azimuth split (one GPU, no collective)"
+            out["projected_rays_per_s_at_world"] = n_rays * emul * args.steps / dt
+            out["roofline"]["traffic"], out["roofline"]["traffic_note"] = None, "full-sweep profile does not apply to a sector"
         if ag_ms is not None:
             out["allgather_ms"] = round(ag_ms, 4)
             out["allgather_bytes_per_rank"] = int(gat.tiles[0].numel() * 4)
