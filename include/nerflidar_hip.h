@@ -385,6 +385,17 @@ int nlr_render_rays_dynamic(const NlrModel *m, const NlrObjects *o, const NlrRay
                             uint32_t N, const NlrRenderCfg *cfg, const NlrOut *out, int32_t *const *winner, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (8) PropMLP density network for training (ZI/models.py:887-889,996-997 with disable_rgb = True):
+ *     raw [M] = W2 relu(W1 f + b1) + b2, f = [M, F] grid features (F = L*C <= 16), nn.Linear layouts W1 [64, F], W2 [1, 64];
+ *     all pointers dev f32 (b2 is the 1-element bias tensor).  The backward recomputes the hidden units (only the features are
+ *     kept between the passes), writes d_feat [M, F] (may be NULL) and OVERWRITES d_w1 [64,F], d_b1 [64], d_w2 [64], d_b2 [1].
+ * ------------------------------------------------------------------------------------------ */
+int nlr_prop_mlp_forward(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, uint32_t M, uint32_t F,
+                         float *raw, void *stream);
+int nlr_prop_mlp_backward(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, const float *g_raw,
+                          uint32_t M, uint32_t F, float *d_feat, float *d_w1, float *d_b1, float *d_w2, float *d_b2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

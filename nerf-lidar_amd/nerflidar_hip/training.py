@@ -399,15 +399,46 @@ class TrainableNerfLevel(torch.nn.Module):
 
 
 # ---- the whole model for training: Model.forward (ZI/models.py:239-576) with autograd, and the step of train.py:272-459 -------------
+class _PropDensity(torch.autograd.Function):
+    """raw density of a PropMLP, `density_layer(feats)[..., 0]`, through `nlr_prop_mlp_forward` / `_backward` (the hidden units are
+    recomputed in the backward: only the features are saved)."""
+
+    @staticmethod
+    def forward(ctx, feats, w1, b1, w2, b2):
+        f = feats.contiguous().float()
+        M, F = f.shape
+        raw = torch.empty(M, device=f.device)
+        ps = [t.detach().contiguous().float() for t in (w1, b1, w2, b2)]
+        with torch.cuda.device(f.device):
+            _lib.check(_lib.lib().nlr_prop_mlp_forward(_lib.ptr(f), *[_lib.ptr(t) for t in ps], M, F, _lib.ptr(raw), _lib.current_stream()),
+                       "nlr_prop_mlp_forward")
+        ctx.save_for_backward(f, *ps)
+        return raw
+
+    @staticmethod
+    def backward(ctx, g):
+        f, w1, b1, w2, b2 = ctx.saved_tensors
+        M, F = f.shape
+        g = g.contiguous().float()
+        d_f = torch.empty_like(f) if ctx.needs_input_grad[0] else None
+        d = [torch.empty_like(t) for t in (w1, b1, w2, b2)]
+        with torch.cuda.device(f.device):
+            _lib.check(_lib.lib().nlr_prop_mlp_backward(_lib.ptr(f), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(g), M, F,
+                                                        _lib.ptr(d_f), *[_lib.ptr(t) for t in d], _lib.current_stream()), "nlr_prop_mlp_backward")
+        return (d_f, *d)
+
+
 class TrainablePropLevel(torch.nn.Module):
     """A PropMLP (ZI/models.py:PropMLP: disable_rgb) with the reference's parameter names: `encoder.embeddings`,
     `density_layer.{0,2}.{weight,bias}`."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, fused: bool = True):
+        """fused: the density network through `nlr_prop_mlp_forward` / `_backward` instead of two library GEMMs with 6-8 wide
+        operands; same parameters, same gradients (fp32 both ways)."""
         super().__init__()
         from .gridencoder import GridEncoder
         nn = torch.nn
-        self.cfg = cfg
+        self.cfg, self.fused = cfg, bool(fused)
         self.encoder = GridEncoder(input_dim=3, num_levels=cfg.grid_num_levels, level_dim=cfg.grid_level_dim,
                                    base_resolution=cfg.grid_base_resolution, desired_resolution=cfg.grid_disired_resolution,
                                    log2_hashmap_size=cfg.grid_log2_hashmap_size, gridtype="hash", align_corners=False)
@@ -417,8 +448,13 @@ class TrainablePropLevel(torch.nn.Module):
 
     def forward(self, batch, tdist, sample_n: int = 7, sample_m: int = 3, rand_deg=None) -> Dict[str, torch.Tensor]:
         means, stds = cast_contract(batch, tdist, sample_n, sample_m, rand_deg=rand_deg)
-        x = self.density_layer(encode_features(self.encoder, means, stds, self.cfg.re_weights))
-        return {"density": torch.nn.functional.softplus(x[..., 0] + self.cfg.density_bias)}
+        feats = encode_features(self.encoder, means, stds, self.cfg.re_weights)
+        if self.fused and feats.shape[-1] <= 16:
+            l0, l2 = self.density_layer[0], self.density_layer[2]
+            raw = _PropDensity.apply(feats.reshape(-1, feats.shape[-1]), l0.weight, l0.bias, l2.weight, l2.bias).reshape(feats.shape[:-1])
+        else:
+            raw = self.density_layer(feats)[..., 0]
+        return {"density": torch.nn.functional.softplus(raw + self.cfg.density_bias)}
 
 
 class TrainableModel(torch.nn.Module):
@@ -435,7 +471,7 @@ class TrainableModel(torch.nn.Module):
         super().__init__()
         self.mc = mc
         for i in range(mc.num_levels - 1):
-            self.add_module(f"prop_mlp_{i}", TrainablePropLevel(mc.prop_cfg(i)))
+            self.add_module(f"prop_mlp_{i}", TrainablePropLevel(mc.prop_cfg(i), fused=fused_mlp))
         import dataclasses
         ncfg = dataclasses.replace(mc.nerf_mlp, use_semantic=mc.config.use_semantic, use_intensity=mc.config.use_intensity,
                                    no_sem_layer=mc.config.no_sem_layer)

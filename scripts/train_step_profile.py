@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(ROOT, "nerf-lidar_amd")); sys.path.insert(0, ROO
 import torch
 from nerflidar_hip import config as nconfig, lidar as nlidar, weights as nweights, training as ntrain
 mc = nconfig.workload(sys.argv[1]); sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
-b = nlidar.synthetic_sweep(width=128, seed=0)
+b = nlidar.synthetic_sweep(width=int(sys.argv[2]) // 32 if len(sys.argv) > 2 else 128, seed=0)
 batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
 n = batch["origins"].shape[0]
 batch.update(rgb=torch.rand(n, 3, device="cuda"), depth=torch.rand(n, device="cuda") * 0.5 + 0.05, semantic=torch.randint(0, 19, (n,), device="cuda"))

@@ -440,3 +440,24 @@ def test_training_step_of_the_whole_model(fused):
     m = Model(mc, tm.reference_state_dict(), precision=2)
     r = m.render_rays(batch)[0]
     assert bool(torch.isfinite(r["depth"]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,M", [(6, 64 * 64 * 7 + 13), (8, 4096), (16, 100), (1, 64)])
+def test_fused_prop_density_network_matches_torch(F, M):
+    """`nlr_prop_mlp_forward` / `_backward` (PropMLP density_layer, ZI/models.py:887-889) against the same two nn.Linear in torch:
+    values, feature gradient and all four parameter gradients; M not a multiple of the wave size, F from 1 to 16."""
+    torch.manual_seed(F)
+    dev = "cuda"
+    lin0, lin2 = torch.nn.Linear(F, 64).to(dev), torch.nn.Linear(64, 1).to(dev)
+    feats = torch.randn(M, F, device=dev, requires_grad=True)
+    cot = torch.randn(M, device=dev)
+    ref = lin2(torch.relu(lin0(feats)))[:, 0]
+    g_ref = torch.autograd.grad((ref * cot).sum(), [feats, lin0.weight, lin0.bias, lin2.weight, lin2.bias])
+    got = ntrain._PropDensity.apply(feats, lin0.weight, lin0.bias, lin2.weight, lin2.bias)
+    g_got = torch.autograd.grad((got * cot).sum(), [feats, lin0.weight, lin0.bias, lin2.weight, lin2.bias])
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for name, a, b in zip(("feats", "w1", "b1", "w2", "b2"), g_got, g_ref):
+        assert a.shape == b.shape, name
+        scale = float(b.abs().max()) + 1e-12
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5 * scale + 1e-6, err_msg=name)
