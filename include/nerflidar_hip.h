@@ -396,6 +396,23 @@ int nlr_prop_mlp_forward(const float *feat, const float *w1, const float *b1, co
 int nlr_prop_mlp_backward(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, const float *g_raw,
                           uint32_t M, uint32_t F, float *d_feat, float *d_w1, float *d_b1, float *d_w2, float *d_b2, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (9) The front half of MLP.predict_density as ONE differentiable operator (ZI/models.py:965-979): cast_rays (render.py:129-168),
+ *     contraction (coord.py:51-100), GridEncoder, erf re-weighting and the mean over the multisamples.
+ *     forward:  features [N*S, L*C] f32 from the intervals of tdist [N, S+1] (what nlr_mlp_level feeds its MLP).
+ *     backward: grad_table [sO, C] f32 += d features / d table applied to d_features [N*S, L*C] (accumulates: zero it first).
+ *     The forward materialises nothing of size [N, S, sample_n, L, C]; the backward one such tensor (the per-point feature
+ *     gradients it hands to nlr_grid_encode_backward) in caller-provided scratch.  The sample positions carry no gradient
+ *     (Model.stop_level_grad); rand_deg as in NlrRenderCfg; f32 grad table.
+ * ------------------------------------------------------------------------------------------ */
+int nlr_encode_features_forward(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n, uint32_t sample_m,
+                                float std_scale, const float *rand_deg, const NlrGridDesc *grid, uint32_t re_weights, float *features,
+                                void *stream);
+int nlr_encode_features_backward(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n, uint32_t sample_m,
+                                 float std_scale, const float *rand_deg, const NlrGridDesc *grid, uint32_t re_weights,
+                                 const float *d_features, float *points_tmp /* [N*S*sample_n, 3] scratch */,
+                                 float *grad_tmp /* [N*S*sample_n, L*C] scratch */, float *grad_table, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -303,6 +303,90 @@ __global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParam
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward of the fused features (training path), first half: per multisample point, its unit-cube position and the gradient of
+// its level features, d_feat[m, l, :] * w_erf_j(l) / n - cast + contraction + re-weighting recomputed, one lane per (sample,
+// multisample).  The scatter into the table is then nlr_grid_encode_backward (run-length aggregated atomics, LDS accumulation of
+// the small dense levels).  A scatter fused into this kernel (one lane walking all levels, or blockIdx.y = level) was built and
+// measured 3-4x slower than the two-kernel form: it loses the LDS accumulation of the hot dense levels and half of the run
+// lengths (an inactive 8th lane in every group of multisamples).
+// ---------------------------------------------------------------------------------------------
+int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist, const float *rand_deg, uint32_t N,
+                         uint32_t S, uint32_t n, uint32_t mloops, float std_scale);
+int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, int piece_major, hipStream_t st);
+
+__global__ void __launch_bounds__(256) nlr_encode_expand_kernel(CastParams cp, GridParams gp, int re_weights, const float *__restrict__ d_feat,
+                                                               float *__restrict__ x01, float *__restrict__ g_pts) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t M = (size_t)cp.N * cp.S;
+    if (t >= M * cp.n) return;
+    const uint32_t m = (uint32_t)(t / cp.n), j = (uint32_t)(t - (size_t)m * cp.n);
+    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    float o[3], d[3], bx[3], by[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = cp.origins[(size_t)ray * 3 + c];
+        d[c] = cp.directions[(size_t)ray * 3 + c];
+        bx[c] = cp.base_x[(size_t)ray * 3 + c];
+        by[c] = cp.base_y[(size_t)ray * 3 + c];
+    }
+    const float t0 = cp.tdist[(size_t)ray * (cp.S + 1) + k], t1 = cp.tdist[(size_t)ray * (cp.S + 1) + k + 1];
+    const Gauss g = nlr_cast_one(cp, ray, k, j, t0, t1, o, d, bx, by, cp.radii[ray]);
+    x01[t * 3 + 0] = g.x0;
+    x01[t * 3 + 1] = g.x1;
+    x01[t * 3 + 2] = g.x2;
+    const float inv_s8 = __frsqrt_rn(8.0f * (g.zs * g.zs));
+    const float inv_n = 1.0f / (float)cp.n;
+    const uint32_t LC = gp.L * gp.C;
+    const float *gf = d_feat + (size_t)m * LC;
+    float *out = g_pts + t * LC;
+    for (uint32_t l = 0; l < gp.L; ++l) {
+        const float w = (re_weights ? nlr_erf_weight_fast(inv_s8, gp.inv_gsize[l]) : 1.0f) * inv_n;
+        for (uint32_t c = 0; c < gp.C; ++c) out[l * gp.C + c] = gf[l * gp.C + c] * w;
+    }
+}
+
+static int encode_features_args(CastParams *cp, GridParams *gp, const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n,
+                                uint32_t sample_m, float std_scale, const float *rand_deg, const NlrGridDesc *grid) {
+    NLR_CHECK_ARG(grid && grid->table && grid->offsets && tdist, "encode_features: NULL argument");
+    int rc = nlr_fill_cast_params(cp, rays, tdist, rand_deg, N, S, sample_n, sample_m, std_scale);
+    if (rc) return rc;
+    return nlr_fill_grid_params(gp, grid->table, grid->table_dtype, grid->offsets, grid->num_levels, grid->level_dim, grid->log2_per_level_scale,
+                                grid->base_resolution, grid->gridtype, (int)grid->align_corners, grid->interp);
+}
+
+extern "C" int nlr_encode_features_forward(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n, uint32_t sample_m,
+                                           float std_scale, const float *rand_deg, const NlrGridDesc *grid, uint32_t re_weights, float *features,
+                                           void *stream) {
+    if (N == 0 || S == 0) return NLR_OK;
+    NLR_CHECK_ARG(features, "encode_features_forward: NULL output");
+    CastParams cp;
+    GridParams gp;
+    int rc = encode_features_args(&cp, &gp, rays, tdist, N, S, sample_n, sample_m, std_scale, rand_deg, grid);
+    if (rc) return rc;
+    return nlr_launch_encode(cp, gp, (int)re_weights, features, 0, (hipStream_t)stream);
+}
+
+extern "C" int nlr_encode_features_backward(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n, uint32_t sample_m,
+                                            float std_scale, const float *rand_deg, const NlrGridDesc *grid, uint32_t re_weights,
+                                            const float *d_features, float *points_tmp, float *grad_tmp, float *grad_table, void *stream) {
+    if (N == 0 || S == 0) return NLR_OK;
+    NLR_CHECK_ARG(d_features && grad_table && points_tmp && grad_tmp, "encode_features_backward: NULL tensor");
+    CastParams cp;
+    GridParams gp;
+    int rc = encode_features_args(&cp, &gp, rays, tdist, N, S, sample_n, sample_m, std_scale, rand_deg, grid);
+    if (rc) return rc;
+    const size_t B = (size_t)N * S * sample_n;
+    NLR_CHECK_ARG(B < (1ull << 32), "encode_features_backward: %zu multisample points do not fit the 32-bit point index", B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nlr_encode_expand_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, cp, gp, (int)re_weights, d_features, points_tmp,
+                       grad_tmp);
+    NLR_LAUNCH_CHECK("nlr_encode_expand_kernel");
+    return nlr_grid_encode_backward(grad_tmp, points_tmp, grid->offsets, grad_table, (uint32_t)B, 3, grid->level_dim, grid->num_levels,
+                                    grid->log2_per_level_scale, grid->base_resolution, nullptr, nullptr, grid->gridtype, (int)grid->align_corners,
+                                    grid->interp, 1, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Rows a-5 / a-6 alone (training path, nerflidar_hip/training.py): the contracted multisample means / bound and stds / bound
 // that MLP.predict_density hands to the GridEncoder (ZI/models.py:965-973), one thread per (sample, multisample).
 // ---------------------------------------------------------------------------------------------

@@ -62,3 +62,47 @@ __device__ __forceinline__ void nlr_level_accum(const GridParams &gp, uint32_t l
     else nlr_level_accum_m<T, C, 2>(gp, level, g, werf, acc);
 }
 
+
+// ---- atomics of a backward pass over ray-ordered points -----------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float nlr_dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// Run-length aggregation.  The points of a batch arrive in ray order (ray, sample, multisample): neighbouring lanes of a channel
+// are neighbouring points on one ray and, on every level coarser than their spacing, fall into the same cell - a wave would send
+// runs of atomics to one address, which the memory pipeline serialises.  A segmented inclusive scan over the runs of equal
+// address inside each 16-lane row (DPP row_shr; the kernel lays a wave out channel-major, so the stride is 1 and lanes of
+// different channels never share an address) leaves every run's sum in its last lane, and only that lane issues the atomic.  Correct for any address sequence: only contiguous equal addresses are merged.
+template <int CTRL>
+__device__ __forceinline__ uint32_t nlr_dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int C>
+__device__ __forceinline__ void nlr_run_atomic(float *gt, uint32_t addr, float v, bool valid, int lane) {
+    const int r = lane & 15;
+    const uint32_t key = valid ? addr : 0xffffffffu - (uint32_t)lane;  // invalid lanes never match a neighbour
+    if (!valid) v = 0.0f;
+    // head of a run: no lane C to the left in the row, or a different address there
+    constexpr int SHR = 0x110;  // row_shr:n = 0x110 + n
+    constexpr int SHL = 0x100;  // row_shl:n = 0x100 + n
+    const uint32_t left = nlr_dpp_u<SHR + C>(key);
+    uint32_t head = (r < C || left != key) ? 1u : 0u;
+    const uint32_t right_head = nlr_dpp_u<SHL + C>(head);
+    const bool tail = (r >= 16 - C) || right_head != 0u;
+#define NLR_RUN_STEP(D)                                          \
+    if constexpr ((D) < 16) {                                      \
+        const float vo = nlr_dpp_f<SHR + (D)>(v);                 \
+        const uint32_t ho = r < (D) ? 1u : nlr_dpp_u<SHR + (D)>(head); \
+        if (!head) {                                               \
+            v += vo;                                               \
+            head = ho;                                             \
+        }                                                          \
+    }
+    NLR_RUN_STEP(C)
+    NLR_RUN_STEP(2 * C)
+    NLR_RUN_STEP(4 * C)
+    NLR_RUN_STEP(8 * C)
+#undef NLR_RUN_STEP
+    if (valid && tail) atomicAdd(gt + addr, v);
+}
+

@@ -84,7 +84,8 @@ EXPORTS = ["nlr_last_error", "nlr_version", "nlr_grid_encode_forward", "nlr_grid
            "nlr_profile_begin", "nlr_profile_end", "nlr_range_workspace_bytes", "nlr_range_project",
            "nlr_composite_backward", "nlr_hash_decay_forward", "nlr_hash_decay_backward", "nlr_box_winner", "nlr_cast_contract",
            "nlr_track_box_params", "nlr_objects_create", "nlr_objects_destroy", "nlr_objects_workspace_bytes", "nlr_objects_apply",
-           "nlr_render_rays_dynamic", "nlr_prop_mlp_forward", "nlr_prop_mlp_backward",
+           "nlr_render_rays_dynamic", "nlr_prop_mlp_forward", "nlr_prop_mlp_backward", "nlr_encode_features_forward",
+           "nlr_encode_features_backward",
            "nlr_train_plan_create", "nlr_train_plan_destroy", "nlr_train_act_width", "nlr_train_param_layout", "nlr_train_pack",
            "nlr_mlp_train_forward", "nlr_mlp_train_backward"]
 NLR_K_COUNT = 6
@@ -150,6 +151,10 @@ def lib():
                                               C.POINTER(NlrOut), C.POINTER(c_fp), c_fp, C.c_size_t, c_fp]
         L.nlr_prop_mlp_forward.argtypes = [c_fp] * 5 + [C.c_uint32, C.c_uint32, c_fp, c_fp]
         L.nlr_prop_mlp_backward.argtypes = [c_fp] * 6 + [C.c_uint32, C.c_uint32] + [c_fp] * 6
+        L.nlr_encode_features_forward.argtypes = [C.POINTER(NlrRays), c_fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, c_fp,
+                                                  C.POINTER(NlrGridDesc), C.c_uint32, c_fp, c_fp]
+        L.nlr_encode_features_backward.argtypes = [C.POINTER(NlrRays), c_fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, c_fp,
+                                                   C.POINTER(NlrGridDesc), C.c_uint32, c_fp, c_fp, c_fp, c_fp, c_fp]
         L.nlr_train_plan_create.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int] + [C.c_float] * 4 + [C.POINTER(c_fp), C.POINTER(C.c_uint32)]
         L.nlr_train_plan_destroy.restype = None
         L.nlr_train_plan_destroy.argtypes = [c_fp]

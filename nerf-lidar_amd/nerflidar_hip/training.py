@@ -169,6 +169,71 @@ def encode_features(encoder, means: torch.Tensor, stds: torch.Tensor, re_weights
     return f.flatten(-2, -1)
 
 
+class _EncodeFeatures(torch.autograd.Function):
+    """cast_rays -> contraction -> GridEncoder -> erf re-weighting -> mean over the multisamples (ZI/models.py:965-979) as one
+    operator: `nlr_encode_features_forward` (the fused kernel of the inference path) and `nlr_encode_features_backward`
+    (per-point feature gradients in one kernel, then the grid operator's scatter).  Differentiable with respect to the table only: sample positions carry
+    no gradient in training (`Model.stop_level_grad`)."""
+
+    @staticmethod
+    def forward(ctx, table, encoder, batch, tdist, sample_n, sample_m, std_scale, rand_deg, re_weights):
+        from .models import _RAY_KEYS
+        n, S = tdist.shape[0], tdist.shape[1] - 1
+        dev = tdist.device
+        if not (table.is_cuda and tdist.is_cuda):
+            raise RuntimeError("encode_features: CUDA tensors required (no CPU fallback)")
+        keep = [batch[k].reshape(n, -1).contiguous().float() for k in _RAY_KEYS]
+        td = tdist.detach().contiguous().float()
+        rd = None if rand_deg is None else rand_deg.reshape(n, S, sample_n).contiguous().float()
+        tab = table.detach().contiguous()
+        ctx.args = (encoder, keep, td, rd, int(sample_n), int(sample_m), float(std_scale), int(bool(re_weights)))
+        ctx.save_for_backward(tab)
+        feats = torch.empty(n * S, encoder.output_dim, device=dev)
+        rays, gd = _EncodeFeatures._descs(encoder, keep, tab)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nlr_encode_features_forward(C.byref(rays), _lib.ptr(td), n, S, sample_n, sample_m, float(std_scale), _lib.ptr(rd),
+                                                              C.byref(gd), int(bool(re_weights)), _lib.ptr(feats), _lib.current_stream()),
+                       "nlr_encode_features_forward")
+        return feats.reshape(n, S, encoder.output_dim)
+
+    @staticmethod
+    def _descs(encoder, keep, tab):
+        from .models import _RAY_KEYS
+        rays = _lib.NlrRays()
+        for k, t in zip(_RAY_KEYS, keep):
+            setattr(rays, k, t.data_ptr())
+        gd = _lib.NlrGridDesc()
+        gd.table, gd.table_dtype = tab.data_ptr(), {torch.float32: 0, torch.float16: 1}[tab.dtype]
+        gd.num_levels, gd.level_dim = encoder.num_levels, tab.shape[1]
+        gd.base_resolution = int(encoder.base_resolution)
+        gd.log2_per_level_scale = float(np.log2(encoder.per_level_scale))
+        gd.offsets = encoder._offsets_host.data_ptr()
+        gd.gridtype, gd.align_corners, gd.interp = encoder.gridtype_id, int(bool(encoder.align_corners)), encoder.interp_id
+        return rays, gd
+
+    @staticmethod
+    def backward(ctx, g):
+        (tab,) = ctx.saved_tensors
+        encoder, keep, td, rd, sample_n, sample_m, std_scale, re_w = ctx.args
+        n, S = td.shape[0], td.shape[1] - 1
+        g = g.reshape(n * S, -1).contiguous().float()
+        grad = torch.zeros(tab.shape, device=tab.device, dtype=torch.float32)
+        pts = torch.empty(n * S * sample_n, 3, device=tab.device)                      # scratch: unit-cube positions of the multisamples
+        gpt = torch.empty(n * S * sample_n, encoder.output_dim, device=tab.device)     # scratch: their feature gradients
+        rays, gd = _EncodeFeatures._descs(encoder, keep, tab)
+        with torch.cuda.device(tab.device):
+            _lib.check(_lib.lib().nlr_encode_features_backward(C.byref(rays), _lib.ptr(td), n, S, sample_n, sample_m, std_scale, _lib.ptr(rd),
+                                                               C.byref(gd), re_w, _lib.ptr(g), _lib.ptr(pts), _lib.ptr(gpt), _lib.ptr(grad),
+                                                               _lib.current_stream()), "nlr_encode_features_backward")
+        return (grad.to(tab.dtype),) + (None,) * 8
+
+
+def encode_features_fused(encoder, batch, tdist, sample_n: int = 7, sample_m: int = 3, std_scale: float = 0.35, rand_deg=None,
+                          re_weights: bool = True) -> torch.Tensor:
+    """[N, S, L*C] features of the intervals of `tdist`: `cast_contract` + `encode_features` in one kernel each way."""
+    return _EncodeFeatures.apply(encoder.embeddings, encoder, batch, tdist, sample_n, sample_m, std_scale, rand_deg, re_weights)
+
+
 # ---- fused NerfMLP for training: nlr_mlp_train_forward / nlr_mlp_train_backward (csrc/nlr_mlp_train.hip) ---------------------------
 class _FusedMLP(torch.autograd.Function):
     """The Linear stack of ZI/models.py:1116-1251 (density trunk, heads, view MLP, rgb) as two MFMA-chain kernels.  The weight
@@ -303,6 +368,7 @@ class TrainableNerfLevel(torch.nn.Module):
         nn = torch.nn
         self.cfg = cfg
         self.fused_mlp = bool(fused_mlp)
+        self.fused_encode = bool(fused_mlp)  # cast + encode + re-weight + mean as one operator (encode_features_fused)
         self._plan = None
         if self.fused_mlp and cfg.use_semantic and cfg.no_sem_layer:
             raise NotImplementedError("fused training MLP: no_sem_layer=True is not wired (use fused_mlp=False)")
@@ -338,10 +404,14 @@ class TrainableNerfLevel(torch.nn.Module):
         from .objects import _pos_enc
         F = torch.nn.functional
         cfg = self.cfg
-        means, stds = cast_contract(batch, tdist, sample_n, sample_m, rand_deg=rand_deg)
+        if self.fused_encode:
+            feats = encode_features_fused(self.encoder, batch, tdist, sample_n, sample_m, rand_deg=rand_deg, re_weights=cfg.re_weights)
+        else:
+            means, stds = cast_contract(batch, tdist, sample_n, sample_m, rand_deg=rand_deg)
+            feats = encode_features(self.encoder, means, stds, cfg.re_weights)
         if self.fused_mlp:
-            return self._forward_fused(batch, encode_features(self.encoder, means, stds, cfg.re_weights))
-        x = self.density_layer(encode_features(self.encoder, means, stds, cfg.re_weights))
+            return self._forward_fused(batch, feats)
+        x = self.density_layer(feats)
         out = {"density": F.softplus(x[..., 0] + cfg.density_bias)}
         if cfg.use_semantic:
             out["semantic"] = torch.softmax(x[..., 1:1 + cfg.class_num] if cfg.no_sem_layer else self.sem_layer(x), -1)
@@ -447,8 +517,11 @@ class TrainablePropLevel(torch.nn.Module):
     load_reference = TrainableNerfLevel.load_reference
 
     def forward(self, batch, tdist, sample_n: int = 7, sample_m: int = 3, rand_deg=None) -> Dict[str, torch.Tensor]:
-        means, stds = cast_contract(batch, tdist, sample_n, sample_m, rand_deg=rand_deg)
-        feats = encode_features(self.encoder, means, stds, self.cfg.re_weights)
+        if self.fused:
+            feats = encode_features_fused(self.encoder, batch, tdist, sample_n, sample_m, rand_deg=rand_deg, re_weights=self.cfg.re_weights)
+        else:
+            means, stds = cast_contract(batch, tdist, sample_n, sample_m, rand_deg=rand_deg)
+            feats = encode_features(self.encoder, means, stds, self.cfg.re_weights)
         if self.fused and feats.shape[-1] <= 16:
             l0, l2 = self.density_layer[0], self.density_layer[2]
             raw = _PropDensity.apply(feats.reshape(-1, feats.shape[-1]), l0.weight, l0.bias, l2.weight, l2.bias).reshape(feats.shape[:-1])

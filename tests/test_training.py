@@ -461,3 +461,31 @@ def test_fused_prop_density_network_matches_torch(F, M):
         assert a.shape == b.shape, name
         scale = float(b.abs().max()) + 1e-12
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5 * scale + 1e-6, err_msg=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,rand", [("nerf", False), ("prop0", False), ("nerf", True)])
+def test_fused_encode_features_matches_the_torch_chain(which, rand):
+    """`nlr_encode_features_forward` / `_backward` (cast -> contract -> grid -> erf re-weight -> mean, ZI/models.py:965-979, one
+    kernel each way) against `cast_contract` + `encode_features` (HIP cast kernel, grid operator with its own backward, torch ops for
+    the re-weighting and the mean): features and the table gradient."""
+    from nerflidar_hip.gridencoder import GridEncoder
+    mc, sd, batch = _ref_scene(log2_hashmap=14, width=16)
+    cfg = mc.nerf_mlp if which == "nerf" else mc.prop_cfg(0)
+    enc = GridEncoder(input_dim=3, num_levels=cfg.grid_num_levels, level_dim=cfg.grid_level_dim, base_resolution=cfg.grid_base_resolution,
+                      desired_resolution=cfg.grid_disired_resolution, log2_hashmap_size=cfg.grid_log2_hashmap_size, init_std=0.5).cuda()
+    n, S = batch["origins"].shape[0], 48
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    td = torch.sort(torch.rand(n, S + 1, device="cuda", generator=gen) * 1.2 + 0.01, dim=-1)[0]
+    rd = torch.rand(n, S, 7, device="cuda", generator=gen) if rand else None
+    cot = torch.randn(n, S, enc.output_dim, device="cuda", generator=gen)
+    means, stds = ntrain.cast_contract(batch, td, rand_deg=rd)
+    ref = ntrain.encode_features(enc, means, stds, True)
+    (g_ref,) = torch.autograd.grad((ref * cot).sum(), [enc.embeddings])
+    got = ntrain.encode_features_fused(enc, batch, td, rand_deg=rd, re_weights=True)
+    (g_got,) = torch.autograd.grad((got * cot).sum(), [enc.embeddings])
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-6, rtol=2e-5)
+    scale = float(g_ref.abs().max())
+    assert scale > 0
+    np.testing.assert_allclose(g_got.cpu().numpy(), g_ref.cpu().numpy(), rtol=0, atol=2e-5 * scale)
