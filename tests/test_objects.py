@@ -254,3 +254,38 @@ def test_device_side_object_branch_has_no_host_synchronisation():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(got["depth"], want["depth"]) and torch.equal(got["semantic"], want["semantic"])
+
+
+@pytest.mark.gpu
+def test_object_abi_error_paths():
+    """Error behaviour of the device-side object API (header section 7b): enumerated status + message, nothing launched."""
+    import ctypes as C
+    from nerflidar_hip import _lib
+    g = golden("obj_REF_small")
+    mc, b, cids, cfgs, sd = _scene(g)
+    mc.config.instance_obj = True
+    model = nobj.DynamicModel(mc, sd, g["tracks"], NAMES, obj_log2_hashmap=int(g["log2_hashmap"]))
+    L = _lib.lib()
+    n, S = 64, 16
+    dev = "cuda"
+    rays = _lib.NlrRays()
+    keep = {k: torch.zeros(n, 3 if k in ("origins", "directions", "viewdirs", "base_x", "base_y") else 1, device=dev) for k in
+            ("origins", "directions", "viewdirs", "radii", "near", "far", "base_x", "base_y")}
+    for k, t in keep.items():
+        setattr(rays, k, t.data_ptr())
+    td = torch.linspace(0, 1, S + 1, device=dev).repeat(n, 1).contiguous()
+    dens = torch.zeros(n, S, device=dev)
+    ws = torch.empty(int(L.nlr_objects_workspace_bytes(model._objects, n, S)), dtype=torch.uint8, device=dev)
+    box3 = torch.zeros(n, 3, 8, device=dev)
+    box3[..., 0] = 1.0          # cos
+    box3[..., 2:5] = 5.0        # box centres far from the (all-zero) rays
+    box3[..., 5:8] = 10.0       # boxes of half-size 0.1
+    box2 = torch.zeros(n, 2, 8, device=dev)
+    call = lambda box, nobjs, wsb: L.nlr_objects_apply(model._objects, C.byref(rays), _lib.ptr(td), _lib.ptr(box), n, S, nobjs, _lib.ptr(dens), None,
+                                                       None, 0, None, _lib.ptr(ws), wsb, None)
+    assert call(box2, 2, ws.numel()) == -1 and b"3 tracks" in L.nlr_last_error()           # track count of the object set
+    assert call(box3, 3, 16) == -4 and b"workspace" in L.nlr_last_error()                 # NLR_ERR_WORKSPACE
+    assert call(box3, 3, ws.numel()) == 0                                                  # no sample inside any box: nothing is touched
+    torch.cuda.synchronize()
+    assert float(dens.abs().max()) == 0.0
+    assert L.nlr_track_box_params(_lib.ptr(model.tracks), _lib.ptr(td), n, 3, 1, _lib.ptr(box3), None) == -1 and b"T = 1" in L.nlr_last_error()
