@@ -204,7 +204,7 @@ class GridEncoder(nn.Module):
         """grid.py:176-198: add the total-variation gradient of the cells under `inputs` (default: B uniform random points) to
         `embeddings.grad`; call it after loss.backward() and before optimizer.step()."""
         if self.embeddings.grad is None:
-            raise ValueError('grad is None, should be called after loss.backward() and before optimizer.step()!')
+            raise ValueError('embeddings.grad is None: the total-variation gradient is added to an existing gradient (call it between backward and the optimiser step)')
         table = self.embeddings
         if inputs is None:
             x01 = torch.rand(B, self.input_dim, device=table.device)
