@@ -37,7 +37,7 @@ enum {
 
 /* MLP arithmetic (NlrModelDesc.mlp_precision) */
 enum {
-    NLR_PREC_F32 = 0,   /* every layer on exact-f32 MFMA (v_mfma_f32_32x32x2_f32): reference-grade */
+    NLR_PREC_F32 = 0,   /* every layer on exact-f32 MFMA (v_mfma_f32_16x16x4_f32): reference-grade */
     NLR_PREC_MIXED = 1, /* density/semantic/intensity layers f32 MFMA, view-MLP bf16 MFMA */
     NLR_PREC_FAST = 2   /* density/semantic/intensity layers split-bf16 (hi+lo, 3 MFMAs), view bf16: the default of the Python host side, bench.py and smoke() */
 };
@@ -215,6 +215,12 @@ int nlr_render_rays(const NlrModel *m, const NlrRays *rays, uint32_t N, const Nl
 /* Comma-separated names of the kernels the library launches, in NLR_K_* order (host only), so that
  * bench.py can match rocprofv3 --kernel-trace rows. */
 const char *nlr_kernel_names(void);
+
+/* SHA-256 (hex) of the kernel sources this BINARY was compiled from (every file under csrc/, this header, the Makefile; the hash of
+ * nerflidar_hip/buildinfo.py), fixed at compile time.  bench.py stamps its JSON line with it and quotes PMC traffic only from a
+ * profile that recorded the same value; a library that is stale against the sources next to it is detectable
+ * (buildinfo.kernel_source_sha() != nlr_build_sha()). */
+const char *nlr_build_sha(void);
 
 /* Per-kernel timing with HIP events recorded on the SAME stream the kernels are launched on.
  * nlr_profile_begin arms the model: every launch made by nlr_render_rays / nlr_mlp_level is then

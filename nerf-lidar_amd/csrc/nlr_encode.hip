@@ -12,6 +12,7 @@
 #include "nlr_kernels.h"
 
 #include "nlr_grid_level.h"
+#include "nlr_level_fast.h"
 
 
 
@@ -191,7 +192,7 @@ __device__ __forceinline__ float nlr_group8_sum(float v) {
 }
 
 template <typename T, int C>
-__global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat,
+__global__ void __launch_bounds__(256) nlr_encode8g_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat,
                                                           int piece_major) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = cp.N * cp.S;
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridPar
 // Proposal level: features as above, then the 64-unit density MLP split over the 8 lanes of the group (8 hidden
 // units per lane) and a final butterfly for the raw density.
 template <typename T, int C, int LMAX>
-__global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParams gp, PropMlpParams mp, int re_weights,
+__global__ void __launch_bounds__(256) nlr_prop8g_kernel(CastParams cp, GridParams gp, PropMlpParams mp, int re_weights,
                                                         float *__restrict__ density, float *__restrict__ feat_out) {
     __shared__ float sw[64 * 16 + 128];  // w1 [64, F] | b1 [64] | w2 [64]
     for (uint32_t i = threadIdx.x; i < 64 * mp.F; i += 256) sw[i] = mp.w1[i];
@@ -298,6 +299,136 @@ __global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParam
     const float raw = nlr_group8_sum(part) + mp.b2;
     if (in && j == 0) {
         const float x = raw + mp.density_bias;
+        density[m] = x > 20.0f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20), models.py:1116
+    }
+}
+
+// =============================================================================================================
+// Round-3 forms of the two kernels above on the level body of nlr_level_fast.h (grids it covers: linear interpolation,
+// align_corners = False, every level dense or hashed with a power-of-two table - all grids of the path's configurations);
+// the ...8g kernels stay for everything else.  Same lane mapping, same arithmetic per point; what changed is the
+// instruction stream (see nlr_level_fast.h) and that a lane's validity (active multisample, point inside the unit cube) is decided
+// once instead of once per level.
+// =============================================================================================================
+struct RayRegs {
+    float o[3], d[3], bx[3], by[3], radius, t0, t1;
+};
+__device__ __forceinline__ RayRegs nlr_load_ray(const CastParams &cp, uint32_t ray, uint32_t k) {
+    RayRegs r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        r.o[c] = cp.origins[(size_t)ray * 3 + c];
+        r.d[c] = cp.directions[(size_t)ray * 3 + c];
+        r.bx[c] = cp.base_x[(size_t)ray * 3 + c];
+        r.by[c] = cp.base_y[(size_t)ray * 3 + c];
+    }
+    r.radius = cp.radii[ray];
+    r.t0 = cp.tdist[(size_t)ray * (cp.S + 1) + k];
+    r.t1 = cp.tdist[(size_t)ray * (cp.S + 1) + k + 1];
+    return r;
+}
+
+template <typename T, int C>
+__global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat,
+                                                          int piece_major) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = cp.N * cp.S;
+    uint32_t m = gt >> 3;
+    const uint32_t j = gt & 7;
+    const bool in = m < M;
+    if (!in) m = M - 1;
+    const bool active = in && j < cp.n;
+    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    const RayRegs rr = nlr_load_ray(cp, ray, k);
+    const Gauss g = nlr_cast_one(cp, ray, k, active ? j : 0, rr.t0, rr.t1, rr.o, rr.d, rr.bx, rr.by, rr.radius);
+    // gridencoder.cu:124-135: a point outside [0,1]^3 encodes as zeros on every level
+    const bool valid = active && !((g.x0 < 0 || g.x0 > 1) || (g.x1 < 0 || g.x1 > 1) || (g.x2 < 0 || g.x2 > 1));
+    const float inv_s8 = __frsqrt_rn(8.0f * (g.zs * g.zs));  // v_rsq_f32 (1 ulp) for 1/sqrtf (30 instructions)
+    const float inv_n = 1.0f / (float)cp.n;
+    float r[C];  // this lane's contribution to the level; stays 0 in lanes without a point
+#pragma unroll
+    for (int c = 0; c < C; ++c) r[c] = 0.0f;
+    for (uint32_t l = 0; l < gp.L; ++l) {
+        if (valid) {
+            const float werf = re_weights ? nlr_erf_weight_fast(inv_s8, gp.inv_gsize[l]) : 1.0f;
+            if (gp.mode[l] == 0) nlr_level_fast<T, C, 0>(gp, l, g.x0, g.x1, g.x2, werf, r);
+            else nlr_level_fast<T, C, 1>(gp, l, g.x0, g.x1, g.x2, werf, r);
+        }
+        float a[C];
+        nlr_group8_sum_to(r, a);
+        if (in && j == (l & 7)) {  // spread the row stores over the lanes of the group (layouts: see nlr_encode8g_kernel)
+            float *f = (piece_major && C == 4) ? feat + ((size_t)l * M + m) * 4 : feat + (size_t)m * gp.L * C + l * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) f[c] = a[c] * inv_n;
+        }
+    }
+}
+
+template <typename T, int C, int LMAX>
+__global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParams gp, PropMlpParams mp, int re_weights,
+                                                        float *__restrict__ density, float *__restrict__ feat_out) {
+    __shared__ float sw[64 * 16 + 128];  // w1 [64, F] | b1 [64] | w2 [64]
+    for (uint32_t i = threadIdx.x; i < 64 * mp.F; i += 256) sw[i] = mp.w1[i];
+    if (threadIdx.x < 64) {
+        sw[64 * mp.F + threadIdx.x] = mp.b1[threadIdx.x];
+        sw[64 * mp.F + 64 + threadIdx.x] = mp.w2[threadIdx.x];
+    }
+    __syncthreads();
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = cp.N * cp.S;
+    uint32_t m = gt >> 3;
+    const uint32_t j = gt & 7;
+    const bool in = m < M;
+    if (!in) m = M - 1;
+    const bool active = in && j < cp.n;
+    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    const RayRegs rr = nlr_load_ray(cp, ray, k);
+    const Gauss g = nlr_cast_one(cp, ray, k, active ? j : 0, rr.t0, rr.t1, rr.o, rr.d, rr.bx, rr.by, rr.radius);
+    const bool valid = active && !((g.x0 < 0 || g.x0 > 1) || (g.x1 < 0 || g.x1 > 1) || (g.x2 < 0 || g.x2 > 1));
+    const float inv_s8 = __frsqrt_rn(8.0f * (g.zs * g.zs));
+    const float inv_n = 1.0f / (float)cp.n;
+    float feat[LMAX * C];
+#pragma unroll
+    for (int i = 0; i < LMAX * C; ++i) feat[i] = 0.0f;
+    if (valid) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < (int)gp.L) {
+                const float werf = re_weights ? nlr_erf_weight_fast(inv_s8, gp.inv_gsize[l]) : 1.0f;
+                float a[C];
+                if (gp.mode[l] == 0) nlr_level_fast<T, C, 0>(gp, l, g.x0, g.x1, g.x2, werf, a);
+                else nlr_level_fast<T, C, 1>(gp, l, g.x0, g.x1, g.x2, werf, a);
+#pragma unroll
+                for (int c = 0; c < C; ++c) feat[l * C + c] = a[c];
+            }
+        }
+    }
+    // multisample means of all levels, four values per butterfly block; every lane of the group gets them
+    static_assert((LMAX * C) % 4 == 0, "feature count of the proposal kernel must be a multiple of 4");
+#pragma unroll
+    for (int i = 0; i < LMAX * C; i += 4) {
+        float q[4] = {feat[i], feat[i + 1], feat[i + 2], feat[i + 3]};
+        nlr_group8_sum_n(q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) feat[i + u] = q[u] * inv_n;
+    }
+    if (feat_out && in && j == 0)
+        for (uint32_t i = 0; i < mp.F; ++i) feat_out[(size_t)m * mp.F + i] = feat[i];
+    // hidden unit hu = 8*hh + j: see nlr_prop8g_kernel
+    float part = 0.0f;
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) {
+        const uint32_t hu = hh * 8 + j;
+        float a = sw[64 * mp.F + hu];
+#pragma unroll
+        for (int i = 0; i < LMAX * C; ++i)
+            if (i < (int)mp.F) a = fmaf(sw[hu * mp.F + i], feat[i], a);
+        part = fmaf(sw[64 * mp.F + 64 + hu], fmaxf(a, 0.0f), part);
+    }
+    float praw[1] = {part};
+    nlr_group8_sum_n(praw);
+    if (in && j == 0) {
+        const float x = (praw[0] + mp.b2) + mp.density_bias;
         density[m] = x > 20.0f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20), models.py:1116
     }
 }
@@ -461,7 +592,12 @@ int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights
     const uint32_t M = cp.N * cp.S;
     if (cp.n <= 8) {  // multisample-parallel mapping
         dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
-#define NLR_ENC8(T, C) hipLaunchKernelGGL((nlr_encode8_kernel<T, C>), grid8, block8, 0, st, cp, gp, re_weights, feat, piece_major)
+        const bool fast = nlr_level_fast_ok(gp);
+#define NLR_ENC8(T, C)                                                                                                               \
+    do {                                                                                                                             \
+        if (fast) hipLaunchKernelGGL((nlr_encode8_kernel<T, C>), grid8, block8, 0, st, cp, gp, re_weights, feat, piece_major);       \
+        else hipLaunchKernelGGL((nlr_encode8g_kernel<T, C>), grid8, block8, 0, st, cp, gp, re_weights, feat, piece_major);           \
+    } while (0)
         if (gp.table_dtype == 0) {
             switch (gp.C) {
                 case 1: NLR_ENC8(float, 1); break;
@@ -516,7 +652,12 @@ int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1,
     NLR_CHECK_ARG(mp.F <= 16, "proposal MLP: L*C = %u > 16 features is outside the fused proposal kernel", mp.F);
     if (cp.n <= 8) {
         dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
-#define NLR_PROP8(T, C, LM) hipLaunchKernelGGL((nlr_prop8_kernel<T, C, LM>), grid8, block8, 0, st, cp, gp, mp, re_weights, density, feat_out)
+        const bool fast = nlr_level_fast_ok(gp);
+#define NLR_PROP8(T, C, LM)                                                                                                                    \
+    do {                                                                                                                                       \
+        if (fast) hipLaunchKernelGGL((nlr_prop8_kernel<T, C, LM>), grid8, block8, 0, st, cp, gp, mp, re_weights, density, feat_out);           \
+        else hipLaunchKernelGGL((nlr_prop8g_kernel<T, C, LM>), grid8, block8, 0, st, cp, gp, mp, re_weights, density, feat_out);               \
+    } while (0)
         const bool f32t = gp.table_dtype == 0;
         if (gp.C == 1 && gp.L <= 8) { if (f32t) NLR_PROP8(float, 1, 8); else NLR_PROP8(__half, 1, 8); }
         else if (gp.C == 1) { if (f32t) NLR_PROP8(float, 1, 16); else NLR_PROP8(__half, 1, 16); }

@@ -220,6 +220,12 @@ extern "C" int nlr_grid_encode_forward(const float *inputs, const void *embeddin
 #undef NLR_DISPATCH_C
 }
 
+// Dense levels whose table fits an LDS copy are accumulated there by nlr_grid_bwd_lds_kernel (below) when the batch is large; both
+// kernels decide with this one predicate.
+#define NLR_LDS_TABLE_FLOATS 36864  // 144 KiB
+__host__ __device__ __forceinline__ bool nlr_level_fits_lds(const GridParams &gp, uint32_t level, uint32_t C) {
+    return gp.mode[level] == 0 && gp.hsize[level] * C <= NLR_LDS_TABLE_FLOATS;
+}
 // One lane per (point, channel): the C channel atomics of a corner go out in ONE instruction as C adjacent lanes on C
 // consecutive floats, so a 64-lane atomic touches 64/C table entries instead of 64 - the L2 atomic path is paid per
 // distinct line (the per-point form spent C instructions of 64 scattered lines each on the same bytes).
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(256) nlr_grid_bwd_kernel(const float *__restri
     constexpr uint32_t P = 64 / C;
     const uint32_t b0 = (t >> 6) * P + ((uint32_t)lane % P), ch = (uint32_t)lane / P;
     const uint32_t level = blockIdx.y;
-    if (lds_levels && gp.mode[level] == 0 && gp.hsize[level] * C <= 36864) return;  // accumulated in LDS by nlr_grid_bwd_lds_kernel
+    if (lds_levels && nlr_level_fits_lds(gp, level, C)) return;  // accumulated in LDS by nlr_grid_bwd_lds_kernel
     const bool inb = b0 < B;
     // (no early exit per lane: the run scan reads its neighbours through DPP, inactive lanes would read as zero keys)
     const uint32_t b = inb ? b0 : B - 1;
@@ -279,10 +285,6 @@ __global__ void __launch_bounds__(256) nlr_grid_bwd_kernel(const float *__restri
 // thousand cells, and their global atomics serialise on those addresses (level 0 of the C = 4 grid cost 3.0 of the 8.6 ms of a
 // 1.8 M-point backward).  Here a workgroup accumulates its share of the points in an LDS copy of the level (ds_add_f32) and adds
 // the copy to the table once: global atomics per level = cells x workgroups instead of points x 8 corners.
-#define NLR_LDS_TABLE_FLOATS 36864  // 144 KiB
-__host__ __device__ __forceinline__ bool nlr_level_fits_lds(const GridParams &gp, uint32_t level, uint32_t C) {
-    return gp.mode[level] == 0 && gp.hsize[level] * C <= NLR_LDS_TABLE_FLOATS;
-}
 template <int C>
 __global__ void __launch_bounds__(1024) nlr_grid_bwd_lds_kernel(const float *__restrict__ grad, const float *__restrict__ x, GridParams gp,
                                                                float *__restrict__ grad_table, uint32_t B, int grad_layout) {
@@ -358,6 +360,9 @@ extern "C" int nlr_grid_encode_backward(const float *grad, const float *inputs, 
     NLR_CHECK_ARG(grad && inputs && grad_embeddings, "grid_encode_backward: NULL tensor");
     NLR_CHECK_ARG((dy_dx == nullptr) == (grad_inputs == nullptr), "grid_encode_backward: dy_dx and grad_inputs go together");
     if (B == 0) return NLR_OK;
+    // one lane per (point, channel) with a 32-bit lane index in both scatter kernels
+    NLR_CHECK_ARG((uint64_t)B * C < (1ull << 32), "grid_encode_backward: B * C = %llu (point, channel) pairs do not fit the 32-bit lane index",
+                  (unsigned long long)B * C);
     GridParams gp;
     int rc = nlr_fill_grid_params(&gp, grad_embeddings, 0, offsets_host, L, C, S, H, gridtype, align_corners, interp);
     if (rc) return rc;

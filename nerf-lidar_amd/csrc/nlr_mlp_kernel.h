@@ -1212,6 +1212,15 @@ __global__ void __launch_bounds__(256, 1) nlr_mlp_kernel(MlpParams P) {
         };
         pass(ic<0>{});
         pass(ic<1>{});
+        // Both halves have read their staged inputs: fetch the next tile's.  (Round 2 staged only a workgroup's FIRST tile on this
+        // path, so with more tiles than workgroups - more than 65 536 samples on 256 CUs - every later tile of a workgroup was
+        // evaluated on its first tile's features: found by the full-size parity run, tests/test_fullsize_parity.py.)  Nothing
+        // overlaps this wait; the exact-f32 chain is the reference-grade mode, not the fast one.
+        if (staged && tile + gridDim.x < ntiles) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stage_issue(tile + gridDim.x);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     }  // tile loop
     // the read-ahead DMA must not outlive the workgroup's LDS allocation

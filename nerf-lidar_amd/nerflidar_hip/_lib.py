@@ -78,7 +78,7 @@ class NlrOut(C.Structure):
 
 _lib = None
 
-EXPORTS = ["nlr_last_error", "nlr_version", "nlr_grid_encode_forward", "nlr_grid_encode_backward", "nlr_grad_total_variation", "nlr_level_scale",
+EXPORTS = ["nlr_last_error", "nlr_version", "nlr_build_sha", "nlr_grid_encode_forward", "nlr_grid_encode_backward", "nlr_grad_total_variation", "nlr_level_scale",
            "nlr_sample_u", "nlr_model_create", "nlr_model_destroy", "nlr_model_set_table", "nlr_workspace_bytes",
            "nlr_render_rays", "nlr_kernel_names", "nlr_resample_level", "nlr_mlp_level", "nlr_composite_level",
            "nlr_profile_begin", "nlr_profile_end", "nlr_range_workspace_bytes", "nlr_range_project",
@@ -100,6 +100,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.nlr_last_error.restype = C.c_char_p
         L.nlr_kernel_names.restype = C.c_char_p
+        L.nlr_build_sha.restype = C.c_char_p
         L.nlr_version.restype = C.c_int
         L.nlr_workspace_bytes.restype = C.c_size_t
         L.nlr_workspace_bytes.argtypes = [c_fp, C.c_uint32]

@@ -1,8 +1,9 @@
 """Identity of the kernel sources a binary / a profile belongs to.
 
-`kernel_source_sha()` hashes everything `make -C nerf-lidar_amd` compiles (csrc/*, the public header, the Makefile).
-bench.py stamps it into its JSON line and only quotes PMC traffic from a profile that recorded the same hash
-(scripts/pmc_traffic.sh writes it), so a stale profile can never pass for a measurement of the benched code."""
+`kernel_source_sha()` hashes everything `make -C nerf-lidar_amd` compiles (csrc/*, the public header, the Makefile).  The Makefile
+compiles that value INTO libnerflidar_hip.so; `binary_sha()` reads it back (`nlr_build_sha()`).  bench.py stamps its JSON line
+with the BINARY's value and only quotes PMC traffic from a profile that recorded the same one (scripts/pmc_traffic.sh writes it),
+so neither a stale profile nor a stale library can pass for a measurement of the benched code; `stale()` names the mismatch."""
 from __future__ import annotations
 
 import glob
@@ -24,6 +25,20 @@ def kernel_source_sha() -> str:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     return h.hexdigest()
+
+
+def binary_sha() -> str:
+    """The source hash compiled into the loaded libnerflidar_hip.so."""
+    from . import _lib
+    return _lib.lib().nlr_build_sha().decode()
+
+
+def stale():
+    """None when the loaded library was built from the sources lying next to it, else a sentence naming the two hashes."""
+    b, s = binary_sha(), kernel_source_sha()
+    if b == s:
+        return None
+    return f"libnerflidar_hip.so was built from kernel source {b[:12]}, the sources in the tree are {s[:12]}: the library is stale"
 
 
 if __name__ == "__main__":

@@ -60,10 +60,11 @@ class _Backend:
         if half is None:
             raise RuntimeError("embeddings must be a floating tensor (float32 or float16)")
         off = _host_offsets(offsets)
-        _lib.check(_lib.lib().nlr_grid_encode_forward(
-            _lib.ptr(inputs), _lib.ptr(embeddings), half, _lib.ptr(off), _lib.ptr(outputs), B, D, C, L, float(S), int(H),
-            _lib.ptr(dy_dx), int(gridtype), int(bool(align_corners)), int(interp), int(out_layout),
-            _lib.current_stream()), "grid_encode_forward")
+        with torch.cuda.device(inputs.device):  # launch on the stream of the tensors' device, not of whatever device is current
+            _lib.check(_lib.lib().nlr_grid_encode_forward(
+                _lib.ptr(inputs), _lib.ptr(embeddings), half, _lib.ptr(off), _lib.ptr(outputs), B, D, C, L, float(S), int(H),
+                _lib.ptr(dy_dx), int(gridtype), int(bool(align_corners)), int(interp), int(out_layout),
+                _lib.current_stream()), "grid_encode_forward")
 
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
@@ -72,10 +73,11 @@ class _Backend:
         _device_operand(inputs, "inputs")
         _device_operand(grad_embeddings, "grad_embeddings")
         off = _host_offsets(offsets)
-        _lib.check(_lib.lib().nlr_grid_encode_backward(
-            _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(off), _lib.ptr(grad_embeddings), B, D, C, L, float(S), int(H),
-            _lib.ptr(dy_dx), _lib.ptr(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp),
-            int(grad_layout), _lib.current_stream()), "grid_encode_backward")
+        with torch.cuda.device(inputs.device):
+            _lib.check(_lib.lib().nlr_grid_encode_backward(
+                _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(off), _lib.ptr(grad_embeddings), B, D, C, L, float(S), int(H),
+                _lib.ptr(dy_dx), _lib.ptr(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp),
+                int(grad_layout), _lib.current_stream()), "grid_encode_backward")
 
     @staticmethod
     def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
@@ -85,9 +87,10 @@ class _Backend:
         if not (inputs.dtype == embeddings.dtype == grad.dtype == torch.float32):
             raise RuntimeError("grad_total_variation runs in float32 (grid.py:176 disables autocast for it)")
         off = _host_offsets(offsets)
-        _lib.check(_lib.lib().nlr_grad_total_variation(
-            _lib.ptr(inputs), _lib.ptr(embeddings), _lib.ptr(grad), _lib.ptr(off), float(weight), B, D, C, L, float(S), int(H),
-            int(gridtype), int(bool(align_corners)), _lib.current_stream()), "grad_total_variation")
+        with torch.cuda.device(inputs.device):
+            _lib.check(_lib.lib().nlr_grad_total_variation(
+                _lib.ptr(inputs), _lib.ptr(embeddings), _lib.ptr(grad), _lib.ptr(off), float(weight), B, D, C, L, float(S), int(H),
+                int(gridtype), int(bool(align_corners)), _lib.current_stream()), "grad_total_variation")
 
 
 _backend = _Backend()

@@ -291,6 +291,31 @@ class Model:
     __call__ = forward
 
 
+class CapturedRender:
+    """One `Model.render_rays` call (the whole static sweep: ~10 kernel launches, no host read-back) captured into a HIP graph.
+
+    A LiDAR simulator renders sweep after sweep from ray buffers it refills in place, so the launch sequence never changes; replaying
+    it costs one graph launch instead of ~10 kernel launches plus their argument marshalling (at 8 azimuth sectors a rank's step is
+    ~1 ms of GPU work against ~0.3 ms of host enqueue).  The ray batch, the optional `packed` tile and the returned output
+    tensors are the buffers of the captured call: refill the inputs in place, `replay()`, read `out` / `hist`."""
+
+    def __init__(self, model: "Model", batch: Dict[str, torch.Tensor], **kw):
+        self.model, self.batch = model, batch
+        side = torch.cuda.Stream(model.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            model.render_rays(batch, **kw)  # sizes the workspace outside the capture
+            side.synchronize()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.out, self.hist = model.render_rays(batch, **kw)
+        torch.cuda.current_stream(model.device).wait_stream(side)
+
+    def replay(self):
+        """Enqueue the captured sweep on the current stream; returns the (static) output dict."""
+        self.graph.replay()
+        return self.out
+
+
 class _SingleProcess:
     """Stand-in for accelerate.Accelerator when rendering in one process."""
     process_index = 0

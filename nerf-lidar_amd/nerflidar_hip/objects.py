@@ -271,7 +271,8 @@ class DynamicModel(Model):
             raise RuntimeError("batch['timestamp'] is missing (ZI/models.py:315)")
         n = batch["origins"].shape[0]
         box = self.box_params(batch["timestamp"], curr_track)
-        winners = [torch.empty(n, S, dtype=torch.int32, device=self.device) for S in self.mc.level_samples()]
+        # -1 = "no track owns this sample": nlr_objects_apply returns before writing when there are no tracks (or no samples)
+        winners = [torch.full((n, S), -1, dtype=torch.int32, device=self.device) for S in self.mc.level_samples()]
         self._dyn_call = (box, winners)
         try:
             r, hist = Model.render_rays(self, batch, train_frac, compute_extras, sample_n, sample_m, want_history, scale_factor, rand_jitter,

@@ -372,6 +372,10 @@ class TrainableNerfLevel(torch.nn.Module):
         self._plan = None
         if self.fused_mlp and cfg.use_semantic and cfg.no_sem_layer:
             raise NotImplementedError("fused training MLP: no_sem_layer=True is not wired (use fused_mlp=False)")
+        if self.fused_mlp and cfg.skip_layer_dir != 0:
+            # the fused kernels wire the skip concatenation into view layer 1 (nlr_mlp_train.hip); another position has the same
+            # parameter count, so nothing downstream would notice (the inference path rejects it too, nlr_api.hip)
+            raise NotImplementedError(f"fused training MLP: skip_layer_dir = {cfg.skip_layer_dir} is not wired, only 0 (use fused_mlp=False)")
         self.encoder = GridEncoder(input_dim=3, num_levels=cfg.grid_num_levels, level_dim=cfg.grid_level_dim,
                                    base_resolution=cfg.grid_base_resolution, desired_resolution=cfg.grid_disired_resolution,
                                    log2_hashmap_size=cfg.grid_log2_hashmap_size, gridtype="hash", align_corners=False)
@@ -447,7 +451,8 @@ class TrainableNerfLevel(torch.nn.Module):
         cfg = self.cfg
         n, S = feats.shape[0], feats.shape[1]
         if self._plan is None:
-            self._plan = _TrainPlan(cfg)
+            with torch.cuda.device(feats.device):  # nlr_train_plan_create allocates on the current device
+                self._plan = _TrainPlan(cfg)
         self._S = S
         params = self._mlp_params()
         assert sum(p.numel() for p in params) == self._plan.n_params
@@ -594,9 +599,20 @@ class TrainableModel(torch.nn.Module):
             rd = torch.rand(n, S, sample_n, device=dev, generator=rand) if randomized else None
             o = level(batch, tdist, sample_n, sample_m, rand_deg=rd)
             rgbs = o["rgb"] if last else torch.zeros(n, S, 3, device=dev)   # a PropMLP renders black (models.py:1119-1122)
+            # background colour (models.py:488-500): the range's value if it is a point, its midpoint for a deterministic render,
+            # otherwise one uniform draw per ray and channel - composited here (the kernel's background is a scalar)
+            lo_bg, hi_bg = mc.bg_intensity_range
+            bg_rand = None
+            if lo_bg == hi_bg:
+                bg = float(lo_bg)
+            elif not randomized:
+                bg = (lo_bg + hi_bg) / 2
+            else:
+                bg, bg_rand = 0.0, torch.rand(n, 3, device=dev, generator=rand) * (hi_bg - lo_bg) + lo_bg
             r = volumetric_render(o["density"], tdist, dirs, rgbs, o.get("semantic") if last else None, o.get("intensity") if last else None,
-                                  bool(mc.opaque_background), mc.bg_intensity_range[0] if mc.bg_intensity_range[0] == mc.bg_intensity_range[1]
-                                  else sum(mc.bg_intensity_range) / 2)
+                                  bool(mc.opaque_background), bg)
+            if bg_rand is not None:
+                r["rgb"] = r["rgb"] + (1.0 - r["acc"]).clamp_min(0.0)[:, None] * bg_rand   # render.py:226-229
             weights = r.pop("weights")
             renderings.append(r)
             history.append(dict(sdist=sdist, tdist=tdist, weights=weights, density=o["density"]))
@@ -604,12 +620,24 @@ class TrainableModel(torch.nn.Module):
         return renderings, history
 
 
+def clip_gradients(model: torch.nn.Module, grad_max_norm: float = 0.0, grad_max_val: float = 0.0) -> None:
+    """train_utils.py:243-253: clip by global norm, then by value, then - unconditionally - replace NaN / +-Inf gradients by
+    0 / the largest finite values (`param.grad.nan_to_num_()`), so that one degenerate ray cannot poison the Adam state."""
+    if grad_max_norm > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), grad_max_norm)
+    if grad_max_val > 0:
+        torch.nn.utils.clip_grad_value_(model.parameters(), grad_max_val)
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.nan_to_num_()
+
+
 def training_step(model: TrainableModel, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], train_frac: float = 1.0,
                   randomized: bool = True, hash_decay_mult: float = 0.1, tv_weight: float = 0.0, grad_max_norm: float = 0.0,
-                  **loss_kw) -> Dict[str, float]:
+                  grad_max_val: float = 0.0, **loss_kw) -> Dict[str, float]:
     """One optimiser step as train.py:272-459 takes it: forward with random jitter, the loss dictionary (`losses.total_loss` +
     hash decay), backward through the HIP backward kernels, optional total-variation gradient on the tables (grid.py:176-198),
-    gradient clipping (train_utils.clip_gradients), step.  Returns the loss terms as floats."""
+    gradient clipping incl. the unconditional nan_to_num_ (train_utils.clip_gradients), step.  Returns the loss terms as floats."""
     from . import losses as nlosses
     optimizer.zero_grad(set_to_none=True)
     renderings, history = model(batch, train_frac=train_frac, randomized=randomized)
@@ -621,8 +649,7 @@ def training_step(model: TrainableModel, optimizer: torch.optim.Optimizer, batch
     if tv_weight > 0:
         for lv in model.levels():
             lv.encoder.grad_total_variation(tv_weight)
-    if grad_max_norm > 0:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), grad_max_norm)
+    clip_gradients(model, grad_max_norm, grad_max_val)
     optimizer.step()
     out = {k: float(v.detach()) for k, v in terms.items()}
     out["loss"] = float(loss.detach())

@@ -31,6 +31,31 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
+_GATE_LOG = os.environ.get("NLR_GATE_LOG")
+
+
+def gate(name, got, ref, mean_tol, max_tol=None, thr=None, frac=0.0):
+    """mean |d| <= mean_tol; the FRACTION of elements with |d| > thr is <= frac (frac = 0: none); max |d| <= max_tol where a hard
+    bound is meaningful.  Fractions replaced round 2's maxima that had been sized to pass (weights 5e-2, semantic 3e-2, percentiles
+    2e-1): an element count beyond a tight threshold detects a defect a loose maximum does not (tests/test_fullsize_parity.py explains
+    the tail).  NLR_GATE_LOG=<file> appends the measured statistics."""
+    d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)).reshape(-1)
+    if _GATE_LOG:
+        with open(_GATE_LOG, "a") as f:
+            f.write(f"{name} n={d.size} mean={d.mean():.3e} p99={np.percentile(d, 99):.3e} max={d.max():.3e} "
+                    f"f>1e-4={np.mean(d > 1e-4):.4f} f>1e-3={np.mean(d > 1e-3):.4f} f>1e-2={np.mean(d > 1e-2):.4f}\n")
+    msg = f"{name}: mean {d.mean():.3e} (<= {mean_tol})"
+    ok = d.mean() <= mean_tol
+    if thr is not None:
+        f_ = float(np.mean(d > thr))
+        msg += f", fraction > {thr}: {f_:.4f} (<= {frac})"
+        ok = ok and f_ <= frac
+    if max_tol is not None:
+        msg += f", max {d.max():.3e} (<= {max_tol})"
+        ok = ok and d.max() <= max_tol
+    assert ok, msg
+
+
 # ------------------------------------------------------------------------------------------------
 # a-7 grid operator through gridencoder.GridEncoder / the C ABI
 # ------------------------------------------------------------------------------------------------
@@ -100,6 +125,48 @@ def test_gridencoder_module_and_backward():
         from nerflidar_hip.gridencoder import _backend
         _backend.grid_encode_forward(torch.zeros(4, 3), enc.embeddings, enc._offsets_host, torch.zeros(4, 12), 4, 3, 2, 6, 1.0, 16,
                                      None, 0, False, 0)
+
+
+@pytest.mark.parametrize("C,order", [(1, "ray"), (4, "ray"), (4, "random"), (2, "random")])
+def test_grid_backward_lds_path_against_oracle(C, order):
+    """`nlr_grid_bwd_lds_kernel` (dense levels accumulated in an LDS copy of the table, taken when B * C >= 2^18: every real training
+    step) against the C restatement of kernel_grid_backward (gridencoder.cu:248-340).  Ray-ordered points (runs of equal cells, the
+    run-length aggregation of the non-LDS levels) and random points (the large-B path had only been compared with itself)."""
+    L, H, log2 = 6, 16, 14
+    from nerflidar_hip import weights as nw
+    offsets, sizes = nw.level_table(L, H, log2)[:2]
+    B = (1 << 18) // C + 4096 + 37           # B * C >= 2^18, not a multiple of anything
+    rng = np.random.default_rng(11)
+    if order == "ray":                       # 512 rays of B/512 consecutive points each
+        n_r = 512
+        o = rng.random((n_r, 1, 3)) * 0.6 + 0.2
+        d = rng.standard_normal((n_r, 1, 3))
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        t = np.linspace(-0.2, 0.2, -(-B // n_r))[None, :, None]
+        x = (o + d * t).reshape(-1, 3)[:B].astype(np.float32)
+    else:
+        x = rng.random((B, 3)).astype(np.float32)
+    x[:16] = _points(16, 5)                  # corners, faces and out-of-range points
+    grad = rng.standard_normal((L, B, C)).astype(np.float32)
+    n_entries = int(offsets[-1])
+    ref, _ = orc.grid_backward_c(grad, x, offsets, n_entries, C, 1.0, H)
+    off = np.ascontiguousarray(offsets, np.int32)
+    gt = torch.zeros(n_entries, C, device=DEV)
+    xd, gd = cu(x), cu(grad)
+    _lib.check(_lib.lib().nlr_grid_encode_backward(_lib.ptr(gd), _lib.ptr(xd), off.ctypes.data, _lib.ptr(gt), B, 3, C, L, 1.0, H, None, None,
+                                                   0, 0, 0, 0, None))
+    torch.cuda.synchronize()
+    got = npy(gt)
+    # float atomics (LDS and global) add in a different order than the oracle's sequential loop: tolerance relative to the sum of
+    # |contributions| of a cell, which for the hot cells of level 0 is thousands of terms
+    ref_abs, _ = orc.grid_backward_c(np.abs(grad), x, offsets, n_entries, C, 1.0, H)
+    err = np.abs(got - ref)
+    assert (err <= 2e-6 * ref_abs + 1e-6).all(), f"max err / sum|terms| {np.max(err / (ref_abs + 1e-3)):.3e}"
+    assert np.abs(ref[: int(offsets[1])]).max() > 1.0  # level 0 (17^3 cells, the LDS level) really received the batch
+    # B * C beyond the 32-bit lane index is refused, not wrapped
+    rc = _lib.lib().nlr_grid_encode_backward(_lib.ptr(gd), _lib.ptr(xd), off.ctypes.data, _lib.ptr(gt), (1 << 30) + 1, 3, 4, L, 1.0, H, None,
+                                             None, 0, 0, 0, 0, None) if C == 4 else -1
+    assert rc != 0
 
 
 @pytest.mark.parametrize("which,log2_hashmap", [("nerf", 14), ("prop1", 12), ("prop0", 21)])
@@ -370,10 +437,6 @@ def test_model_forward(name, precision):
     # levels -> density (x1500 gain at "surfaces") -> weights -> next level's samples.  Gates therefore are the
     # north_star's: depth L1 (mean |d|) <= 1e-3, intensity <= 1e-3, semantic argmax bit-exact; per-sample
     # history is checked on its mean error and a loose max.
-    def gate(name, got, ref, mean_tol, max_tol):
-        d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
-        assert d.mean() <= mean_tol and d.max() <= max_tol, f"{name}: mean {d.mean():.3e} (<= {mean_tol}), max {d.max():.3e} (<= {max_tol})"
-
     for lvl in range(mc.num_levels):
         gate(f"sdist{lvl}", npy(hist[lvl]["sdist"][:K]), g[f"hist{lvl}_sdist"], 1e-5, 2e-3)
         gate(f"tdist{lvl}", npy(hist[lvl]["tdist"][:K]), g[f"hist{lvl}_tdist"], 1e-5, 2e-3)
@@ -413,10 +476,6 @@ def test_render_path_compositing_mode(name):
     batch = {k: cu(v) for k, v in batch_np.items()}
     r, _ = model.render_rays(batch, scale_factor=1 / 250)
     ru, _ = model.render_rays(batch, scale_factor=1 / 250, want_history=True)
-
-    def gate(name, got, ref, mean_tol, max_tol):
-        d = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
-        assert d.mean() <= mean_tol and d.max() <= max_tol, f"{name}: mean {d.mean():.3e} (<= {mean_tol}), max {d.max():.3e} (<= {max_tol})"
 
     gate("depth", npy(r["depth"]), g["out_depth"], 1e-3, 1e-2)
     assert np.percentile(np.abs(npy(r["depth"]) - g["out_depth"]), 95) <= 1e-3
@@ -603,3 +662,33 @@ def test_ragged_ray_counts_are_consistent(wl):
         rn, _ = model.render_rays({k: v[:n].contiguous() for k, v in full.items()}, scale_factor=0.004)
         for k in ("depth", "rgb", "semantic", "labels", "points", "acc", "distance_median"):
             assert torch.equal(rn[k], rf[k][:n]), (wl, n, k)
+
+
+def test_static_sweep_replays_from_a_hip_graph():
+    """`nlr_render_rays` reads nothing back to the host: the whole static sweep (resample / proposal / encode / MLP / composite of
+    every level + the packed azimuth-major tile) is capturable, and a replay after the inputs were refilled in place is bit-identical to
+    an eager call on the new inputs."""
+    from nerflidar_hip.models import CapturedRender, Model
+    mc = nconfig.workload("C2", 14)
+    sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
+    model = Model(mc, sd, device=DEV)
+    H, wp = 8, 24
+    sweeps = [nlidar.synthetic_sweep(width=wp, seed=s_, beams=nlidar.LIDAR_ANGLES[::4]) for s_ in (0, 1)]
+    batch = {k: cu(v) for k, v in sweeps[0].items()}
+    tile = torch.zeros(wp, H, 7, device=DEV)
+    cap = CapturedRender(model, batch, compute_extras=True, scale_factor=1 / 250, packed=tile)
+    for sw in (sweeps[1], sweeps[0]):
+        for k, v in sw.items():
+            batch[k].copy_(cu(v))               # refill the captured input buffers in place
+        tile.zero_()
+        for v in cap.out.values():
+            v.zero_()
+        out = cap.replay()
+        torch.cuda.synchronize()
+        eager_tile = torch.zeros(wp, H, 7, device=DEV)
+        want, _ = model.render_rays({k: cu(v) for k, v in sw.items()}, compute_extras=True, scale_factor=1 / 250, packed=eager_tile)
+        torch.cuda.synchronize()
+        for k in ("depth", "intensity", "semantic", "labels", "rgb", "acc", "points", "distance_median"):
+            assert torch.equal(out[k], want[k]), k
+        assert torch.equal(tile, eager_tile)
+        assert float(tile.abs().sum()) > 0

@@ -113,12 +113,12 @@ def test_azimuth_sector_partition():
     np.testing.assert_array_equal(parts[1][0]["viewdirs"][0], b["viewdirs"][7])
 
 
-def _shard_worker(rank, world, port, tmp):
+def _shard_worker(rank, world, port, tmp, W=22):
     import torch.distributed as dist
     from nerflidar_hip import sharding
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    H, W = 4, 22  # W not divisible by world -> padded columns
+    H = 4
     full = nlidar.synthetic_sweep(width=W, seed=1, beams=nlidar.LIDAR_ANGLES[:H])
 
     def fake_render(b, packed=None):  # deterministic per-ray function standing in for the HIP renderer
@@ -130,6 +130,7 @@ def _shard_worker(rank, world, port, tmp):
     one_r = fake_render({k: torch.from_numpy(v) for k, v in full.items()})
     one = sharding.pack_tile(one_r, H, W)  # azimuth-major [W, H, 7]
     g = sharding.SweepGatherer(H, W, "cpu")
+    assert g.wp == -(-W // world) and g.images[0].shape[0] == g.wp * world  # the gathered buffer carries the padded columns
     for i in range(3):  # double buffering: three sweeps through two buffers
         img = sharding.render_sweep_sharded(fake_render, full, H, W, "cpu", gatherer=g, index=i)
         assert img.shape == (W, H, 7)
@@ -154,6 +155,34 @@ def test_sharded_sweep_world2_gloo(tmp_path):
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
+def test_sharded_sweep_world4_padded_gloo(tmp_path):
+    """A width that really pads: 22 columns over 4 ranks = 6 per rank, 2 padded columns in the last rank's tile, which the
+    gathered image drops (sharding.SweepGatherer.image -> images[b][:width])."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_shard_worker, args=(4, port, str(tmp_path), 22), nprocs=4, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(4))
+
+
+def test_bench_selftest_reference_sweep_8_ranks():
+    """The reference's real sweep shape, 32 x 1100 (ZI/lidar_utils.py:122-134), over 8 CPU ranks: 138 columns per rank, 4 padded."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-cpu", "--steps", "2", "--gpus", "8",
+                        "--selftest-hw", "32", "1100"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["image_equal"] and d["ranks_seen"] == 8 and d["columns_per_rank"] == 138 and d["padded_columns"] == 4
+    assert d["shape"] == [1100, 32, 7]
+
+
 @pytest.mark.parametrize("extra", [["--gpus", "2"], ["--gpus", "2", "--scaling", "weak"], ["--gpus", "1", "--force-dist"]])
 def test_bench_self_launch_cpu(extra):
     """`python bench.py --gpus N` without a launcher environment starts its own N ranks (torch.distributed.run children) and
@@ -168,5 +197,34 @@ def test_bench_self_launch_cpu(extra):
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    assert d["selftest"] and d["image_equal"] and d["n_gpus"] == int(extra[1])
+    assert d["selftest"] and d["image_equal"] and d["n_gpus"] == int(extra[1]) and d["ranks_seen"] == int(extra[1])
     assert d["shape"] == [64 * (2 if "weak" in extra else 1), 4, 7]
+
+
+def test_binary_carries_its_source_hash_and_stale_builds_lose_traffic(tmp_path, monkeypatch):
+    """The source hash is compiled INTO libnerflidar_hip.so (`nlr_build_sha`), bench.py stamps its line with the binary's value and
+    quotes PMC traffic only while binary == sources == profile."""
+    import importlib.util
+    import json
+    from nerflidar_hip import buildinfo
+    b, s_ = buildinfo.binary_sha(), buildinfo.kernel_source_sha()
+    assert len(b) == 64 and b == s_ and buildinfo.stale() is None, "libnerflidar_hip.so is stale against the sources: run make -C nerf-lidar_amd"
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prof = tmp_path / "pmc.json"
+    json.dump({"kernel_source_sha": b, "kernels": {"void nlr_mlp_kernel<8>": {"hbm_read_bytes_corrected": 100.0, "hbm_write_bytes": 5.0}}}, open(prof, "w"))
+    t, note = bench.pmc_traffic(str(prof), b, s_, "nlr_mlp_kernel")
+    assert t == 105.0 and "bytes per launch" in note
+    # a source file edited after the build: the tree's hash moves, the binary's does not -> traffic withheld, mismatch named
+    extra = tmp_path / "tampered.hip"
+    extra.write_text("// edited after the build\n")
+    monkeypatch.setattr(buildinfo, "kernel_source_files", lambda f=buildinfo.kernel_source_files: f() + [str(extra)])
+    s2 = buildinfo.kernel_source_sha()
+    assert s2 != b and "stale" in buildinfo.stale() and b[:12] in buildinfo.stale() and s2[:12] in buildinfo.stale()
+    t, note = bench.pmc_traffic(str(prof), b, s2, "nlr_mlp_kernel")
+    assert t is None and "stale binary" in note and b[:12] in note and s2[:12] in note
+    # a profile of another build
+    json.dump({"kernel_source_sha": "0" * 64, "kernels": {}}, open(prof, "w"))
+    t, note = bench.pmc_traffic(str(prof), b, b, "nlr_mlp_kernel")
+    assert t is None and "was measured on kernel source 000000000000" in note

@@ -154,6 +154,40 @@ def test_grid_numpy_twin_matches_c():
         assert enc.offsets[-1] == sd[f"{prefix}.encoder.embeddings"].shape[0]
 
 
+def test_grid_dense_levels_match_torch_grid_sample():
+    """Independent pin for row a-7 (missing 6): on a DENSE level the hash grid is plain trilinear interpolation of a
+    (res + 1)^3 lattice, and `torch.nn.functional.grid_sample(mode='bilinear', align_corners=True)` is a third-party implementation
+    of exactly that.  Mapping (gridencoder.cu:138-153, grid.py:162): lattice coordinate pos = x01 * scale + 0.5 with scale = res - 1,
+    row index = x + y * (res + 1) + z * (res + 1)^2; grid_sample's normalised coordinate u = 2 * pos / res - 1 lands on the same lattice
+    coordinate.  Checked for the dense levels of all three shipped grids (17^3, 33^3, 65^3 rows), C = 1 and C = 4."""
+    import torch.nn.functional as F
+    mc = nconfig.workload("REF", 21)
+    sd = nweights.synth_state_dict(mc, seed=5, table_std=0.5)
+    rng = np.random.default_rng(1)
+    x = rng.random((20000, 3)).astype(np.float32)
+    x[:8] = np.array([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [0, 1, 0.25], [1, 0, 0], [0.999999, 0.5, 0.5], [1e-7, 1e-7, 1e-7],
+                      [0.25, 0.75, 1.0]], np.float32)
+    checked = 0
+    for prefix, cfg in nweights.mlp_names(mc):
+        enc = orc.make_encoders(sd, mc)[prefix]
+        c_out, _ = orc.grid_encode_c(x, enc.table, enc.offsets, enc.S, enc.H)         # [L, B, C]
+        scale, res = orc.level_scale(enc.num_levels, enc.S, enc.H)
+        C = enc.level_dim
+        for l in range(enc.num_levels):
+            step = int(res[l]) + 1
+            if step ** 3 > int(enc.offsets[l + 1] - enc.offsets[l]):
+                continue                                                              # hashed level: no lattice to sample
+            lat = torch.from_numpy(enc.table[int(enc.offsets[l]):int(enc.offsets[l]) + step ** 3].astype(np.float64))
+            vol = lat.reshape(step, step, step, C).permute(3, 0, 1, 2)[None]           # [1, C, D = z, H = y, W = x]
+            pos = x.astype(np.float64) * float(scale[l]) + 0.5
+            u = torch.from_numpy(2.0 * pos / float(res[l]) - 1.0)[None, None, None]    # [1, 1, 1, B, (x, y, z)]
+            ref = F.grid_sample(vol, u, mode="bilinear", padding_mode="border", align_corners=True)[0, :, 0, 0].T.numpy()
+            # f32 positions / weights in the C checker against float64 here: 1-2 ulp of the lattice coordinate (x scale up to 64)
+            np.testing.assert_allclose(c_out[l], ref, atol=2e-5 * np.abs(lat.numpy()).max(), rtol=0)
+            checked += 1
+    assert checked == 9  # levels 0-2 of PropMLP_0, PropMLP_1 and the NerfMLP grid
+
+
 def test_grid_tv_oracle_matches_numpy_restatement():
     """kernel_grad_tv (gridencoder.cu:506-601) as the C checker states it against an independently written float64 numpy
     version: dense and hashed levels, cells on the level boundary (a missing left / right neighbour), out-of-range points."""
