@@ -5,6 +5,8 @@
 #include <vector>
 
 #include "nlr_kernels.h"
+
+#include <stdlib.h>
 #include "nlr_objects.h"
 
 
@@ -358,6 +360,11 @@ extern "C" int nlr_model_create(const NlrModelDesc *desc, NlrModel **out, void *
             NLR_FAIL(NLR_ERR_HIP, "model_create: cannot query the current device");
         }
         m->cus = (uint32_t)n;
+        // diagnostic: run the persistent MLP grid on fewer workgroups than CUs (power / clock experiments)
+        if (const char *e = getenv("NLR_MLP_WORKGROUPS")) {
+            const int w = atoi(e);
+            if (w > 0 && w < n) m->cus = (uint32_t)w;
+        }
     }
     m->num_levels = desc->num_levels;
     m->dilation_multiplier = desc->dilation_multiplier;

@@ -147,6 +147,32 @@ def intensity_loss(pred: torch.Tensor, target: torch.Tensor, lidar_mask: torch.T
     return 0.1 * d.pow(2).mean() if d.numel() else pred.sum() * 0
 
 
+def nusc_masks(batch: Dict[str, torch.Tensor], lidar_supervision: bool = False, only_lidar_supervision: bool = False,
+               instance_obj: bool = False, aug_road: bool = False) -> Dict[str, torch.Tensor]:
+    """The per-ray masks of a nuScenes batch exactly as train.py:288-324 derives them (dataset_loader == 'nusc'), returned under the keys
+    `total_loss` reads: mask_rgb, depth_mask, sem_mask, lidar_mask (bool).  Reference quirk kept: `batch['mask']` is first replaced by
+    `mask == 0` (a bool) and the colour mask is then `that == 0`, i.e. colour is supervised where the ORIGINAL mask is non-zero."""
+    m = batch["mask"] == 0                                           # train.py:288
+    if instance_obj:
+        m = torch.zeros_like(m)                                      # :290
+    if aug_road:
+        m = m.clone()
+        m[batch["aug_mask"] == 1] = 1                                # :292
+    patch = batch["patch_mask"] if "patch_mask" in batch else torch.zeros_like(batch["mask"])
+    rgb = torch.logical_and(m == 0, patch == 0)                      # :311
+    depth = torch.logical_and(batch["depth"] > 0, rgb)               # :313
+    sem = torch.logical_and(batch["semantic"] != 255, rgb)           # :315
+    lidar = (batch["lidar_mask"] == 1) if "lidar_mask" in batch else torch.zeros_like(rgb)
+    if lidar_supervision:                                            # :317-323
+        rgb, depth, sem = rgb.clone(), depth.clone(), sem.clone()
+        rgb[lidar] = False
+        depth[lidar] = True
+        sem[lidar] = False
+        if only_lidar_supervision:
+            depth[~lidar] = False
+    return dict(mask_rgb=rgb, depth_mask=depth, sem_mask=sem, lidar_mask=lidar)
+
+
 def total_loss(renderings: List[Dict[str, torch.Tensor]], ray_history: List[Dict[str, torch.Tensor]], batch: Dict[str, torch.Tensor], *,
                data_kind: str = "charb", charb_padding: float = 1e-3, data_coarse_mult: float = 0.0, data_mult: float = 1.0,
                interlevel_mult: float = 0.0, anti_interlevel_mult: float = 0.01, pulse_width: Sequence[float] = (0.03, 0.003),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the render kernels: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md, HBM section).
-# Writes gpurun_out/pmc_traffic/summary.json = {"kernel_source_sha": <hash of the sources this binary was built from>,
-# "kernels": {name: {...}}}; copy it to profiles/r02_pmc_traffic.json.  bench.py quotes it only while the hash matches.
+# Writes gpurun_out/pmc_traffic/summary.json = {"kernel_source_sha": <the source hash compiled into the measured binary, nlr_build_sha()>,
+# "kernels": {name: {...}}}; copy it to profiles/r03_pmc_traffic.json.  bench.py quotes it only while the hash matches.
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
 mkdir -p $OUT
@@ -28,5 +28,5 @@ for k, v in res.items():
     if "WRITE_SIZE" in v: v["hbm_write_bytes"] = v["WRITE_SIZE"] * 1024
     if "TCC_HIT_sum" in v: v["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
     print(k, json.dumps(v))
-json.dump({"kernel_source_sha": buildinfo.kernel_source_sha(), "kernels": res}, open("gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
+json.dump({"kernel_source_sha": buildinfo.binary_sha(), "stale": buildinfo.stale(), "kernels": res}, open("gpurun_out/pmc_traffic/summary.json", "w"), indent=1)
 PY

@@ -618,11 +618,133 @@ def gen_losses():
     save("fn_losses", **out)
 
 
+class _RefGridFn(torch.autograd.Function):
+    """Autograd through the CPU restatement of the grid kernels (forward cu:87-199, backward cu:248-340) for the reference import in
+    training mode: gradients reach the embeddings (positions carry none: Model.stop_level_grad)."""
+
+    @staticmethod
+    def forward(ctx, flat, emb, enc):
+        out, _ = orc.grid_encode_c(flat.numpy(), emb.detach().numpy(), enc.offsets.numpy(), float(np.log2(enc.per_level_scale)),
+                                   enc.base_resolution, enc.gridtype_id, enc.align_corners, enc.interp_id)
+        ctx.enc, ctx.flat, ctx.n = enc, flat, emb.shape[0]
+        return torch.from_numpy(out).permute(1, 0, 2).reshape(flat.shape[0], enc.output_dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        enc = ctx.enc
+        gl = g.reshape(g.shape[0], enc.num_levels, enc.level_dim).permute(1, 0, 2).contiguous().numpy()
+        gt, _ = orc.grid_backward_c(gl, ctx.flat.numpy(), enc.offsets.numpy(), ctx.n, enc.level_dim, float(np.log2(enc.per_level_scale)),
+                                    enc.base_resolution, None, enc.gridtype_id, enc.align_corners, enc.interp_id)
+        return None, torch.from_numpy(gt), None
+
+
+class RefGridEncoderTrain(RefGridEncoder):
+    def forward(self, inputs, bound=1):
+        x01 = (inputs + bound) / (2 * bound)
+        prefix = list(x01.shape[:-1])
+        flat = x01.reshape(-1, self.input_dim).detach().contiguous()
+        return _RefGridFn.apply(flat, self.embeddings, self).view(prefix + [self.output_dim])
+
+
+def gen_train_step():
+    """Row f-3, the WHOLE training step (missing 3): the reference's `model(...)` in training mode on one batch, then
+    the reference's OWN loss assembly - lines 283-453 of train.py, read from the file and executed here, not transcribed: masks,
+    data term, depth / semantic / intensity terms, anti-aliased interlevel and distortion terms, their weights - and `.backward()`.
+    Stored: every loss term, the total, and the gradients of named parameters of all three MLPs.  Deterministic sample positions
+    (rand=False): the jitter only moves the samples, the composition of the step is what this pins."""
+    print("training-step fixture")
+    import tempfile
+    import textwrap
+    for name in ("rawpy", "mediapy", "imageio", "tensorboardX", "plyfile", "trimesh", "nuscenes"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                _stub(name)
+    _stub("pycolmap", SceneManager=object)
+    for _ in range(20):
+        try:
+            from internal import train_utils as rtu, configs as rcfg
+            break
+        except ModuleNotFoundError as e:
+            _stub(e.name)
+    mc = nconfig.workload("REF", 12)
+    mc.config.use_intensity = True          # all three heads, so that every term of the assembly is live
+    mc.__post_init__()
+    seed, width = 3, 12
+    sd_np = nweights.synth_state_dict(mc, seed=seed, trained_like=True)
+    rmodels.GridEncoder = RefGridEncoderTrain
+    try:
+        model = build_ref_model(mc, sd_np)
+    finally:
+        rmodels.GridEncoder = RefGridEncoder
+    model.train()
+    beams = nlidar.LIDAR_ANGLES[::4]
+    batch_np = nlidar.synthetic_sweep(width=width, seed=seed, beams=beams)
+    N = batch_np["origins"].shape[0]
+    batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    # supervision of the batch (datasets.py nuScenes loader keys read by train.py:283-424)
+    sup = dict(rgb=rnd(80, 1, (N, 3)), depth=rnd(80, 2, (N,), 0.2, 1.8), intensity=rnd(80, 3, (N,), 0.0, 1.0),
+               semantic=(rnd(80, 4, (N,)) * 19).floor().clamp(0, 18), mask=(rnd(80, 5, (N,)) > 0.7).float(),
+               patch_mask=torch.zeros(N), lidar_mask=(rnd(80, 6, (N,)) > 0.5).float())
+    sup["semantic"][::7] = 255              # unlabelled rays
+    sup["depth"][1::9] = 0.0                # rays without a depth target
+    batch.update({k: v.clone() for k, v in sup.items()})
+    config = rcfg.Config()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "depth"))
+    open(os.path.join(tmp, "depth", "x"), "w").write("1")
+    config.data_dir, config.dataset_loader, config.patch_size = tmp, "nusc", 1
+    config.lidar_supervision, config.only_lidar_supervison, config.pose_refine = True, False, False
+    config.use_semantic, config.use_intensity, config.instance_obj, config.latent_size = True, True, False, 0
+    config.hash_decay_mults, config.symmetrize = 0.0, False
+    train_frac, step = 0.37, 5
+    renderings, ray_history = model(False, batch, train_frac=train_frac, compute_extras=True, sample_n=7, sample_m=3, zero_glo=False,
+                                    step=step, max_step=25000, curr_track=None)
+    src = open(os.path.join(REF, "train.py")).read().split("\n")
+    first = next(i for i, l in enumerate(src) if l.strip() == "losses = {}")
+    last = next(i for i, l in enumerate(src) if l.strip() == "loss = sum(losses.values())")
+    block = textwrap.dedent("\n".join(src[first:last + 1]))
+    ns = dict(torch=torch, nn=nn, os=os, train_utils=rtu, config=config, batch=batch, renderings=renderings, ray_history=ray_history,
+              model=model, module=model, step=step, start_step=config.start_step, end_step=config.end_step, latent_vector_dict={})
+    exec(compile(block, "train.py[%d:%d]" % (first + 1, last + 1), "exec"), ns)
+    losses, loss = ns["losses"], ns["loss"]
+    loss.backward()
+    for p_ in model.parameters():            # train_utils.clip_gradients' unconditional nan_to_num_
+        if p_.grad is not None:
+            p_.grad.nan_to_num_()
+    out = dict(workload=np.array("REF"), log2_hashmap=np.array(12), seed=np.array(seed), width=np.array(width), beams=np.array(beams),
+               train_frac=np.float32(train_frac), loss=loss.detach(), train_py_lines=np.array([first + 1, last + 1]),
+               anti_mult=np.float32(config.anti_interlevel_loss_mult), inter_mult=np.float32(config.interlevel_loss_mult),
+               dist_mult=np.float32(config.distortion_loss_mult), pulse_width=np.asarray(config.pulse_width, np.float32),
+               data_loss_type=np.array(config.data_loss_type), charb_padding=np.float32(config.charb_padding),
+               data_coarse_mult=np.float32(config.data_coarse_loss_mult), data_mult=np.float32(config.data_loss_mult),
+               mask_rgb=batch["mask_rgb"])
+    for k, v in losses.items():
+        out["loss_" + k] = v.detach()
+    for k, v in sup.items():
+        out["sup_" + k] = v
+    out["out_depth"], out["out_rgb"] = renderings[-1]["depth"].detach(), renderings[-1]["rgb"].detach()
+    named = dict(model.named_parameters())
+    for k in ("nerf_mlp.density_layer.0.weight", "nerf_mlp.density_layer.2.bias", "nerf_mlp.lin_second_stage_0.weight",
+              "nerf_mlp.lin_second_stage_1.weight", "nerf_mlp.rgb_layer.weight", "nerf_mlp.sem_layer.2.weight",
+              "nerf_mlp.intensity_layer.0.weight", "nerf_mlp.encoder.embeddings", "prop_mlp_0.density_layer.0.weight",
+              "prop_mlp_0.encoder.embeddings", "prop_mlp_1.density_layer.2.weight", "prop_mlp_1.encoder.embeddings"):
+        g = named[k].grad
+        assert g is not None and float(g.abs().sum()) > 0, k
+        out["grad_" + k] = g
+    print("   loss terms:", {k: float(v) for k, v in losses.items()}, "total", float(loss))
+    save("train_step_REF", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     if os.environ.get("NLR_GOLDEN_ONLY") == "losses":
         gen_losses()
+        raise SystemExit(0)
+    if os.environ.get("NLR_GOLDEN_ONLY") == "train_step":
+        gen_train_step()
         raise SystemExit(0)
     if os.environ.get("NLR_GOLDEN_ONLY") == "f4":
         gen_raydrop_apply()
@@ -643,4 +765,5 @@ if __name__ == "__main__":
     gen_raydrop_apply()
     gen_checkpoint()
     gen_losses()
+    gen_train_step()
     print("done")

@@ -34,6 +34,16 @@ def npy(t):
 _GATE_LOG = os.environ.get("NLR_GATE_LOG")
 
 
+def _gate_distance(name, got, ref, key):
+    """distance_mean / median / percentiles per ray (48-96 rays per fixture).  The percentiles interpolate the CDF: where it is flat
+    (empty space between two surfaces) a 1e-6 change of a weight moves the crossing a long way on that ray, so they get a ray-count
+    gate at 1e-2 (measured: at most 1 ray of a fixture beyond it, max 2.8e-2) instead of round 2's maximum of 2e-1."""
+    if key in ("distance_mean", "distance_median"):
+        gate(name, got, ref, 2e-4, 1e-2, thr=1e-3, frac=0.035)
+    else:
+        gate(name, got, ref, 1e-3, 1e-1, thr=1e-2, frac=0.035)
+
+
 def gate(name, got, ref, mean_tol, max_tol=None, thr=None, frac=0.0):
     """mean |d| <= mean_tol; the FRACTION of elements with |d| > thr is <= frac (frac = 0: none); max |d| <= max_tol where a hard
     bound is meaningful.  Fractions replaced round 2's maxima that had been sized to pass (weights 5e-2, semantic 3e-2, percentiles
@@ -391,6 +401,7 @@ def test_mlp_level(name, precision):
     # density against the reference: the pre-activation carries the feature error above times the x1500 "trained-like" gain of
     # density_layer.2 row 0, hence the loose gate here ...
     np.testing.assert_allclose(npy(dens), g["density"], atol=5e-2, rtol=2e-3)
+    gate("density_level", npy(dens), g["density"], 5e-3, thr=1e-2, frac=0.05)
     # ... and the tight one on the MLP arithmetic itself: the trunk in float64 on the features the GPU produced, tolerance relative
     # to the gain sum_j |W2[0,j] h_j| of the raw density (split-bf16: ~2^-16 per product; exact-f32 MFMA: f32 rounding)
     f64 = npy(feat).astype(np.float64)
@@ -438,31 +449,32 @@ def test_model_forward(name, precision):
     # north_star's: depth L1 (mean |d|) <= 1e-3, intensity <= 1e-3, semantic argmax bit-exact; per-sample
     # history is checked on its mean error and a loose max.
     for lvl in range(mc.num_levels):
-        gate(f"sdist{lvl}", npy(hist[lvl]["sdist"][:K]), g[f"hist{lvl}_sdist"], 1e-5, 2e-3)
-        gate(f"tdist{lvl}", npy(hist[lvl]["tdist"][:K]), g[f"hist{lvl}_tdist"], 1e-5, 2e-3)
-        gate(f"weights{lvl}", npy(hist[lvl]["weights"][:K]), g[f"hist{lvl}_weights"], 1e-4, 5e-2)
-        gate(f"depth{lvl}", npy(rend[lvl]["depth"]), g[f"lvl{lvl}_depth"], 1e-3, 1e-2)
+        # (measured over all fixtures x precisions, r03: sdist max 7.9e-5, tdist 1.3e-4, weights 1.7e-3 with 0.07 % beyond 1e-3)
+        gate(f"sdist{lvl}", npy(hist[lvl]["sdist"][:K]), g[f"hist{lvl}_sdist"], 1e-5, 1e-3, thr=1e-4, frac=0.002)
+        gate(f"tdist{lvl}", npy(hist[lvl]["tdist"][:K]), g[f"hist{lvl}_tdist"], 1e-5, 1e-3, thr=1e-4, frac=0.004)
+        gate(f"weights{lvl}", npy(hist[lvl]["weights"][:K]), g[f"hist{lvl}_weights"], 2e-5, 1e-2, thr=1e-3, frac=0.004)
+        gate(f"depth{lvl}", npy(rend[lvl]["depth"]), g[f"lvl{lvl}_depth"], 2e-4, 1e-2, thr=1e-3, frac=0.035)
         if f"lvl{lvl}_rgb" in g:  # the whole rendering dict of a proposal level (ZI/models.py:514-531)
             gate(f"rgb{lvl}", npy(rend[lvl]["rgb"]), g[f"lvl{lvl}_rgb"], 1e-6, 1e-5)
             gate(f"acc{lvl}", npy(rend[lvl]["acc"]), g[f"lvl{lvl}_acc"], 1e-6, 1e-5)
             for k in ("distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
-                gate(f"{k}{lvl}", npy(rend[lvl][k]), g[f"lvl{lvl}_{k}"], 1e-3, 2e-2 if k == "distance_mean" else 2e-1)
-    gate("depth", npy(r["depth"]), g["out_depth"], 1e-3, 1e-2)            # depth L1 within 1e-3 of the reference
+                _gate_distance(f"{k}{lvl}", npy(rend[lvl][k]), g[f"lvl{lvl}_{k}"], k)
+    gate("depth", npy(r["depth"]), g["out_depth"], 2e-4, 1e-2, thr=1e-3, frac=0.035)   # depth L1 within 1e-3 of the reference (measured <= 4e-5)
     assert np.percentile(np.abs(npy(r["depth"]) - g["out_depth"]), 95) <= 1e-3
     # percentiles interpolate the CDF: where it is flat (empty space between two surfaces) a 1e-6 change of a weight
     # moves the crossing point a long way, so only the mean is held tight
     for k in ("distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
-        gate(k, npy(r[k]), g["out_" + k], 1e-3, 2e-2 if k == "distance_mean" else 2e-1)
+        _gate_distance(k, npy(r[k]), g["out_" + k], k)
     gate("acc", npy(r["acc"]), g["out_acc"], 1e-6, 1e-5)
     if "out_intensity" in g:
         gate("intensity", npy(r["intensity"]), g["out_intensity"], 1e-4, 1e-3)  # intensity within 1e-3
     if "out_semantic" in g:
-        gate("semantic", npy(r["semantic"]), g["out_semantic"], 1e-4, 3e-2)
+        gate("semantic", npy(r["semantic"]), g["out_semantic"], 1e-4, 1e-2, thr=1e-3, frac=0.01)  # measured: max 3.5e-3, 0.4 % beyond 1e-3
         np.testing.assert_array_equal(npy(r["semantic"]).argmax(-1), g["out_semantic"].argmax(-1))  # bit-exact labels
     if precision == _lib.PREC_F32:
-        gate("rgb", npy(r["rgb"]), g["out_rgb"], 2e-4, 2e-2)
+        gate("rgb", npy(r["rgb"]), g["out_rgb"], 2e-4, 5e-3, thr=1e-3, frac=0.02)
     else:
-        gate("rgb", npy(r["rgb"]), g["out_rgb"], 2e-3, 3e-2)  # bf16 view MLP: 8 mantissa bits per layer, 8 layers
+        gate("rgb", npy(r["rgb"]), g["out_rgb"], 2e-3, 2e-2)  # bf16 view MLP: 8 mantissa bits per layer, 8 layers (measured max 9.7e-3)
 
 
 @pytest.mark.parametrize("name", _names("fwd_"))
@@ -477,15 +489,15 @@ def test_render_path_compositing_mode(name):
     r, _ = model.render_rays(batch, scale_factor=1 / 250)
     ru, _ = model.render_rays(batch, scale_factor=1 / 250, want_history=True)
 
-    gate("depth", npy(r["depth"]), g["out_depth"], 1e-3, 1e-2)
+    gate("depth", npy(r["depth"]), g["out_depth"], 2e-4, 1e-2, thr=1e-3, frac=0.035)
     assert np.percentile(np.abs(npy(r["depth"]) - g["out_depth"]), 95) <= 1e-3
     gate("acc", npy(r["acc"]), g["out_acc"], 1e-6, 1e-5)
     if "out_intensity" in g:
         gate("intensity", npy(r["intensity"]), g["out_intensity"], 1e-4, 1e-3)
     if "out_semantic" in g:
-        gate("semantic", npy(r["semantic"]), g["out_semantic"], 1e-4, 3e-2)
+        gate("semantic", npy(r["semantic"]), g["out_semantic"], 1e-4, 1e-2, thr=1e-3, frac=0.01)
         np.testing.assert_array_equal(npy(r["labels"]), g["out_semantic"].argmax(-1))  # bit-exact labels
-    gate("rgb", npy(r["rgb"]), g["out_rgb"], 2e-3, 3e-2)
+    gate("rgb", npy(r["rgb"]), g["out_rgb"], 2e-3, 2e-2)
     for k in ("depth", "acc", "distance_median", "points"):
         np.testing.assert_array_equal(npy(r[k]), npy(ru[k]))
     for k in ("rgb", "semantic", "intensity"):
