@@ -377,7 +377,12 @@ def render_image(model: Model, accelerator, batch, rand, config, train_frac=1, v
     `num_processes`, `gather` (accelerate.Accelerator works).  For LiDAR sweeps on several GPUs prefer
     `sharding.render_sweep_sharded`: one collective per sweep instead of one per key per chunk."""
     if render_instance:
-        raise NotImplementedError("render_instance (obj_rendering) is outside the fused path")
+        # Not a gap of this path: the reference's branch cannot run.  render_image(render_instance=True) -> Model.obj_rendering
+        # (ZI/models.py:579-794) -> obj_utils.box_pts(..., transform=False) (models.py:662), whose transform=False arm is
+        # `import pdb; pdb.set_trace()` followed by a read of the never-assigned `pts_o` (ZI/obj_utils.py:216-217).  Probed by
+        # running the reference here (tests/golden/make_golden.py:probe_obj_rendering): BdbQuit at obj_utils.py:217 <- models.py:662.
+        raise NotImplementedError("render_instance: the reference's Model.obj_rendering stops in a pdb.set_trace() and then reads an unassigned "
+                                  "variable (ZI/obj_utils.py:216-217, reached from ZI/models.py:662); there is no behaviour to reproduce")
     acc = accelerator or _SingleProcess()
     world, rank = acc.num_processes, acc.process_index
     lead = tuple(batch["origins"].shape[:2]) if image else (batch["origins"].shape[0],)

@@ -413,10 +413,9 @@ def gen_composite_grad():
              g_intensity=gi, weights=w.detach(), **{"out_" + k: r[k].detach() for k in ("rgb", "depth", "semantic", "intensity", "acc")})
 
 
-def gen_objects():
-    """Row f-1: the reference `Model` with Config.instance_obj=True (latent mode, shipped ObjMLP gin bindings) on a sweep with
-    three synthetic tracks; per-function fixtures for get_pose / box_pts and the whole forward."""
-    print("dynamic-object fixtures")
+def _build_obj_model():
+    """The reference `Model` with Config.instance_obj=True (latent mode, shipped ObjMLP gin bindings) on a sweep with three synthetic
+    tracks, filled with the synthetic state dict."""
     from internal import obj_utils as robj
     from nerflidar_hip import objects as nobj
     lg, width, seed = 12, 16, 2
@@ -462,6 +461,36 @@ def gen_objects():
     model.load_state_dict(new_sd, strict=False)
     model.eval()
     batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    return model, batch, batch_np, tracks, cids, lg, seed, width, beams
+
+
+def probe_obj_rendering():
+    """Row f: does the reference's `Model.obj_rendering` (models.py:579-794, reached through
+    `render_image(render_instance=True)`) run under the shipped gin (latent mode)?  Prints / returns the outcome."""
+    model, batch, *_ = _build_obj_model()
+    import bdb
+    import traceback
+    stdin = sys.stdin
+    sys.stdin = open(os.devnull)  # the path contains a `pdb.set_trace()`: with no terminal the debugger quits at once (BdbQuit)
+    try:
+        with torch.no_grad():
+            rend, hist = model.obj_rendering(False, batch, train_frac=1.0, compute_extras=True, zero_glo=True, track_id=0)
+        msg = "ran: keys " + ",".join(sorted(rend[-1]))
+    except (Exception, bdb.BdbQuit) as e:  # noqa: BLE001
+        where = [f"{os.path.basename(f.filename)}:{f.lineno}" for f in traceback.extract_tb(e.__traceback__) if "internal" in f.filename]
+        msg = f"raises {type(e).__name__} {str(e).splitlines()[0][:200] if str(e) else ''} at {' <- '.join(reversed(where[-3:]))}"
+    finally:
+        sys.stdin = stdin
+    print("obj_rendering (latent mode, shipped ObjMLP bindings):", msg)
+    return msg
+
+
+def gen_objects():
+    """Row f-1: the reference `Model` with Config.instance_obj=True (latent mode, shipped ObjMLP gin bindings) on a sweep with
+    three synthetic tracks; per-function fixtures for get_pose / box_pts and the whole forward."""
+    print("dynamic-object fixtures")
+    from internal import obj_utils as robj
+    model, batch, batch_np, tracks, cids, lg, seed, width, beams = _build_obj_model()
     with torch.no_grad():
         pose = robj.get_pose(batch["timestamp"], model.tracks)
         rend, hist = model(False, batch, train_frac=1.0, compute_extras=True, zero_glo=True)
@@ -742,6 +771,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if os.environ.get("NLR_GOLDEN_ONLY") == "losses":
         gen_losses()
+        raise SystemExit(0)
+    if os.environ.get("NLR_GOLDEN_ONLY") == "obj_probe":
+        probe_obj_rendering()
         raise SystemExit(0)
     if os.environ.get("NLR_GOLDEN_ONLY") == "train_step":
         gen_train_step()
