@@ -39,6 +39,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C2")
+    ap.add_argument("--width", type=int, default=W_COLS, help="azimuth columns of the sweep (1024 = BASELINE config; 1100 = the reference's own "
+                    "sweep, ZI/lidar_utils.py:122-134: 35 200 rays)")
     ap.add_argument("--precision", type=int, default=2, help="0 f32, 1 mixed, 2 fast (default; see include/nerflidar_hip.h)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = ONE 32x1024 sweep in N azimuth sectors (C4); weak = 1024*N columns")
@@ -230,7 +232,7 @@ def main():
     sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
     model = Model(mc, sd, device=dev, precision=args.precision,
                   table_dtype=torch.float16 if args.table_dtype == "f16" else torch.float32)
-    width = W_COLS * (world if args.scaling == "weak" else 1)
+    width = args.width * (world if args.scaling == "weak" else 1)
     full = nlidar.synthetic_sweep(width=width, seed=0)
     emul = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
     sec, wp = nlidar.azimuth_sector(full, H_BEAMS, width, rank, emul or world)
@@ -323,7 +325,8 @@ def main():
         # COMPILED INTO the binary they measured: a profile of other code is not a measurement of this binary.
         bsha, ssha = buildinfo.binary_sha(), buildinfo.kernel_source_sha()
         prof = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        plain = world == 1 and args.workload == "C2" and not args.chunk and not emul
+        plain = (world == 1 and args.workload == "C2" and not args.chunk and not emul and args.width == W_COLS and args.table_dtype == "f32"
+                 and args.precision == 2 and args.log2_hashmap is None)
         traffic, tnote = pmc_traffic(prof, bsha, ssha, "nlr_mlp_kernel", plain)
         g_traffic, g_note = pmc_traffic(prof, bsha, ssha, "nlr_encode8_kernel", plain)
         # second ceiling: the gather side.  Algorithmic bytes of nlr_encode8_kernel per launch = samples x 7 multisamples x

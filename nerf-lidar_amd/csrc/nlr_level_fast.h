@@ -88,6 +88,65 @@ struct NlrEntry<__half, 8> {
     }
 };
 
+// Dense levels: the x and x + 1 corners are neighbouring entries, so for entries of up to 8 bytes ONE gather instruction fetches both
+// (4 gathers per level instead of 8; the pair is only entry-aligned, which global loads allow).
+template <typename T, int C>
+struct NlrPair {
+    static constexpr bool ok = false;
+    static __device__ __forceinline__ void ld(const char *, uint32_t, float (&)[C], float (&)[C]) {}
+};
+typedef float nlr_float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float nlr_float4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef uint32_t __attribute__((aligned(2))) nlr_u32_a2;
+typedef uint32_t nlr_uint2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t nlr_uint4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+template <>
+struct NlrPair<float, 1> {
+    static constexpr bool ok = true;
+    static __device__ __forceinline__ void ld(const char *base, uint32_t off, float (&a)[1], float (&b)[1]) {
+        const nlr_float2_a4 t = *(const nlr_float2_a4 *)(base + off);
+        a[0] = t.x, b[0] = t.y;
+    }
+};
+template <>
+struct NlrPair<float, 2> {
+    static constexpr bool ok = true;
+    static __device__ __forceinline__ void ld(const char *base, uint32_t off, float (&a)[2], float (&b)[2]) {
+        const nlr_float4_a8 t = *(const nlr_float4_a8 *)(base + off);
+        a[0] = t.x, a[1] = t.y, b[0] = t.z, b[1] = t.w;
+    }
+};
+template <>
+struct NlrPair<__half, 1> {
+    static constexpr bool ok = true;
+    static __device__ __forceinline__ void ld(const char *base, uint32_t off, float (&a)[1], float (&b)[1]) {
+        const __half2 t = __builtin_bit_cast(__half2, (uint32_t) * (const nlr_u32_a2 *)(base + off));
+        a[0] = __low2float(t), b[0] = __high2float(t);
+    }
+};
+template <>
+struct NlrPair<__half, 2> {
+    static constexpr bool ok = true;
+    static __device__ __forceinline__ void ld(const char *base, uint32_t off, float (&a)[2], float (&b)[2]) {
+        const nlr_uint2_a4 t = *(const nlr_uint2_a4 *)(base + off);
+        const __half2 p = __builtin_bit_cast(__half2, t.x), q = __builtin_bit_cast(__half2, t.y);
+        a[0] = __low2float(p), a[1] = __high2float(p), b[0] = __low2float(q), b[1] = __high2float(q);
+    }
+};
+template <>
+struct NlrPair<__half, 4> {
+    static constexpr bool ok = true;
+    static __device__ __forceinline__ void ld(const char *base, uint32_t off, float (&a)[4], float (&b)[4]) {
+        const nlr_uint4_a8 t = *(const nlr_uint4_a8 *)(base + off);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const __half2 p = __builtin_bit_cast(__half2, w[i]), q = __builtin_bit_cast(__half2, w[2 + i]);
+            a[2 * i] = __low2float(p), a[2 * i + 1] = __high2float(p), b[2 * i] = __low2float(q), b[2 * i + 1] = __high2float(q);
+        }
+    }
+};
+
 // Can the fast body run this grid?  (host)
 static inline bool nlr_level_fast_ok(const GridParams &gp) {
     if (gp.interp != 0 || gp.align_corners != 0) return false;
@@ -222,8 +281,13 @@ __device__ __forceinline__ void nlr_level_fast(const GridParams &gp, uint32_t le
             for (int c8 = 0; c8 < 8; ++c8) off[c8] = (((c8 & 1) ? hx1 : hx0) ^ yz[c8 >> 1]) & mask;
         }
         float v[8][C];
+        if constexpr (MODE == 0 && NlrPair<T, C>::ok) {
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) NlrEntry<T, C>::ld(base, off[c8], v[c8]);
+            for (int c8 = 0; c8 < 8; c8 += 2) NlrPair<T, C>::ld(base, off[c8], v[c8], v[c8 + 1]);  // off[c8 + 1] = off[c8] + one entry
+        } else {
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) NlrEntry<T, C>::ld(base, off[c8], v[c8]);
+        }
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
             const float w = (c8 & 1) ? w2[c8 >> 1].y : w2[c8 >> 1].x;
