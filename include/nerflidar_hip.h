@@ -229,6 +229,10 @@ const char *nlr_build_sha(void);
  * launch while armed; nothing when not armed. */
 enum { NLR_K_RESAMPLE = 0, NLR_K_PROP = 1, NLR_K_ENCODE = 2, NLR_K_DIRBIAS = 3, NLR_K_MLP = 4, NLR_K_COMPOSITE = 5, NLR_K_COUNT = 6 };
 int nlr_profile_begin(NlrModel *m);
+/* The same for a subset of the kernel kinds (bit k of kind_mask = NLR_K_k): a pair of event records costs ~4 us of stream time, ten
+ * kernels per sweep make that 0.1 ms of a 7 ms step (profiles/r03_emulated_sector_steps.txt), so bench.py brackets only the two kernels
+ * its roofline objects need inside the timed region and takes the others' durations in a separate, untimed pass. */
+int nlr_profile_begin_kinds(NlrModel *m, uint32_t kind_mask);
 int nlr_profile_end(NlrModel *m, void *stream, float *total_ms, uint32_t *launches);
 
 /* ------------------------------------------------------------------------------------------

@@ -26,13 +26,14 @@ extern "C" const char *nlr_kernel_names(void) {
 // ---- optional per-kernel event timing ---------------------------------------------------------------
 struct Profile {
     bool armed = false;
+    uint32_t mask = 0xffffffffu;  // bit k set: kernels of kind NLR_K_k are bracketed
     std::vector<hipEvent_t> ev;  // start/stop pairs
     std::vector<int> kind;
 };
 struct ProfScope {  // RAII bracket around one launch
     Profile *p;
     hipStream_t st;
-    ProfScope(Profile *prof, int kind, hipStream_t s) : p(prof && prof->armed ? prof : nullptr), st(s) {
+    ProfScope(Profile *prof, int kind, hipStream_t s) : p(prof && prof->armed && ((prof->mask >> kind) & 1u) ? prof : nullptr), st(s) {
         if (!p) return;
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { p = nullptr; return; }
@@ -423,14 +424,16 @@ extern "C" int nlr_model_set_table(NlrModel *m, uint32_t level, const void *tabl
     return NLR_OK;
 }
 
-extern "C" int nlr_profile_begin(NlrModel *m) {
+extern "C" int nlr_profile_begin_kinds(NlrModel *m, uint32_t kind_mask) {
     NLR_CHECK_ARG(m != nullptr, "profile_begin: NULL model");
     for (hipEvent_t e : m->prof.ev) (void)hipEventDestroy(e);
     m->prof.ev.clear();
     m->prof.kind.clear();
+    m->prof.mask = kind_mask;
     m->prof.armed = true;
     return NLR_OK;
 }
+extern "C" int nlr_profile_begin(NlrModel *m) { return nlr_profile_begin_kinds(m, 0xffffffffu); }
 
 extern "C" int nlr_profile_end(NlrModel *m, void *stream, float *total_ms, uint32_t *launches) {
     NLR_CHECK_ARG(m && total_ms && launches, "profile_end: NULL argument");

@@ -81,7 +81,7 @@ _lib = None
 EXPORTS = ["nlr_last_error", "nlr_version", "nlr_build_sha", "nlr_grid_encode_forward", "nlr_grid_encode_backward", "nlr_grad_total_variation", "nlr_level_scale",
            "nlr_sample_u", "nlr_model_create", "nlr_model_destroy", "nlr_model_set_table", "nlr_workspace_bytes",
            "nlr_render_rays", "nlr_kernel_names", "nlr_resample_level", "nlr_mlp_level", "nlr_composite_level",
-           "nlr_profile_begin", "nlr_profile_end", "nlr_range_workspace_bytes", "nlr_range_project",
+           "nlr_profile_begin", "nlr_profile_begin_kinds", "nlr_profile_end", "nlr_range_workspace_bytes", "nlr_range_project",
            "nlr_composite_backward", "nlr_hash_decay_forward", "nlr_hash_decay_backward", "nlr_box_winner", "nlr_cast_contract",
            "nlr_track_box_params", "nlr_objects_create", "nlr_objects_destroy", "nlr_objects_workspace_bytes", "nlr_objects_apply",
            "nlr_render_rays_dynamic", "nlr_prop_mlp_forward", "nlr_prop_mlp_backward", "nlr_encode_features_forward",
@@ -166,6 +166,7 @@ def lib():
         L.nlr_mlp_train_forward.argtypes = [c_fp, c_fp, c_fp, C.c_uint32, C.c_uint32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
         L.nlr_mlp_train_backward.argtypes = [c_fp, C.c_uint32, C.c_uint32] + [c_fp] * 11
         L.nlr_profile_begin.argtypes = [c_fp]
+        L.nlr_profile_begin_kinds.argtypes = [c_fp, C.c_uint32]
         L.nlr_profile_end.argtypes = [c_fp, c_fp, c_fp, c_fp]
         _lib = L
     return _lib
