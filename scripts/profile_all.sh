@@ -3,13 +3,13 @@
 # traffic of every render kernel (separate --pmc passes: gpurun refuses --pmc together with tracing domains), phase stamps.
 # usage (on the GPU box): TAG=r02_final scripts/profile_all.sh     -> gpurun_out/$TAG/*; copy what matters into profiles/
 set -u
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 python3 bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
-python3 nerf-lidar_amd/nerflidar_hip/buildinfo.py > $OUT/kernel_source_sha.txt
+python3 -c "import sys; sys.path.insert(0, \"nerf-lidar_amd\"); from nerflidar_hip import buildinfo; print(buildinfo.binary_sha()); print(\"stale:\", buildinfo.stale())" > $OUT/kernel_source_sha.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 cd $R

@@ -387,6 +387,25 @@ def gen_unet():
             save(f"unet_{tag}", x=x, logits=out[0], reg=out[1])
         else:
             save(f"unet_{tag}", x=x, logits=out)
+    # The mask term of one training iteration (ray_drop_train.py:96-101 with vgg = False: the VGG term needs ImageNet weights that
+    # cannot be fetched here): reference UNet in train mode (BatchNorm on batch statistics), `F.cross_entropy(prediction, gt_mask) * 1.`,
+    # backward.  Stored: loss and the gradients of the first, a middle and the last convolution + a BatchNorm weight.
+    m = RefUNet(n_channels=6, n_classes=2, bilinear=True, regression=False).train()
+    unet_fill(m, 9)
+    x = rnd(9, 30, (4, 6, 32, 64))
+    gt = (rnd(9, 31, (4, 32, 64)) > 0.35).long()
+    pred = m(x)
+    loss = torch.nn.functional.cross_entropy(pred, gt) * 1.
+    loss.backward()
+    named = dict(m.named_parameters())
+    keys = ["inc.double_conv.0.weight", "inc.double_conv.1.weight", "down2.maxpool_conv.1.double_conv.3.weight", "up3.conv.double_conv.0.weight",
+            "outc.conv.weight", "outc.conv.bias"]
+    out = {}
+    for k in keys:  # (fixture size: the first 4 096 values and the norm of each gradient)
+        g_ = named[k].grad.reshape(-1)
+        out["grad_" + k] = g_[:4096].clone()
+        out["gnorm_" + k] = g_.double().norm().float()
+    save("unet_ce_step", x=x, gt_mask=gt, loss=loss.detach(), logits=pred.detach()[:1], **out)
 
 
 def gen_composite_grad():
@@ -771,6 +790,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if os.environ.get("NLR_GOLDEN_ONLY") == "losses":
         gen_losses()
+        raise SystemExit(0)
+    if os.environ.get("NLR_GOLDEN_ONLY") == "unet":
+        gen_unet()
         raise SystemExit(0)
     if os.environ.get("NLR_GOLDEN_ONLY") == "obj_probe":
         probe_obj_rendering()
