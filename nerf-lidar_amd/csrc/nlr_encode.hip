@@ -11,6 +11,8 @@
 // 7-sample mean [N*S, L*C] leaves the kernel (NerfMLP level) or only the density (proposal levels).
 #include "nlr_kernels.h"
 
+#include <stdlib.h>
+
 #include "nlr_grid_level.h"
 #include "nlr_level_fast.h"
 
@@ -588,11 +590,19 @@ int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist
     return NLR_OK;
 }
 
+// Test hook (tests/test_hip_parity.py::test_fast_level_body_is_bit_identical_to_the_generic_one): NLR_ENCODE_GENERIC=1 in the
+// environment sends every launch through the round-2 kernels (nlr_encode8g_kernel / nlr_prop8g_kernel), which otherwise serve only the
+// grids outside the fast body's envelope.  Read per launch: a getenv is nothing next to a kernel launch.
+static bool nlr_force_generic() {
+    const char *e = getenv("NLR_ENCODE_GENERIC");
+    return e && e[0] == '1';
+}
+
 int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, int piece_major, hipStream_t st) {
     const uint32_t M = cp.N * cp.S;
     if (cp.n <= 8) {  // multisample-parallel mapping
         dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
-        const bool fast = nlr_level_fast_ok(gp);
+        const bool fast = nlr_level_fast_ok(gp) && !nlr_force_generic();
 #define NLR_ENC8(T, C)                                                                                                               \
     do {                                                                                                                             \
         if (fast) hipLaunchKernelGGL((nlr_encode8_kernel<T, C>), grid8, block8, 0, st, cp, gp, re_weights, feat, piece_major);       \
@@ -652,7 +662,7 @@ int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1,
     NLR_CHECK_ARG(mp.F <= 16, "proposal MLP: L*C = %u > 16 features is outside the fused proposal kernel", mp.F);
     if (cp.n <= 8) {
         dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
-        const bool fast = nlr_level_fast_ok(gp);
+        const bool fast = nlr_level_fast_ok(gp) && !nlr_force_generic();
 #define NLR_PROP8(T, C, LM)                                                                                                                    \
     do {                                                                                                                                       \
         if (fast) hipLaunchKernelGGL((nlr_prop8_kernel<T, C, LM>), grid8, block8, 0, st, cp, gp, mp, re_weights, density, feat_out);           \

@@ -739,3 +739,34 @@ def test_static_sweep_replays_from_a_hip_graph():
             assert torch.equal(out[k], want[k]), k
         assert torch.equal(tile, eager_tile)
         assert float(tile.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("table_dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("workload,log2", [("C2", 14), ("REF", 21), ("C2", 10)])
+def test_fast_level_body_is_bit_identical_to_the_generic_one(workload, log2, table_dtype):
+    """`csrc/nlr_level_fast.h` (round 3: 32-bit offsets, reduced primes, scalar path for wave-uniform cells, x-pairs on dense levels,
+    asm butterfly) claims the arithmetic of the generic body unchanged.  NLR_ENCODE_GENERIC=1 routes the same launches through the
+    round-2 kernels: every output of a whole render - which passes through nlr_prop8_kernel (C = 1) twice and nlr_encode8_kernel
+    (C = 4) once, dense and hashed levels, fp32 and fp16 tables, 2^10 .. 2^21-entry hash maps - must be the same BITS.  The sweep is
+    wide enough for uniform and non-uniform waves on every level."""
+    from nerflidar_hip.models import Model
+    mc = nconfig.workload(workload, log2)
+    sd = nweights.synth_state_dict(mc, seed=2, trained_like=True)
+    model = Model(mc, sd, device=DEV, table_dtype=table_dtype)
+    batch = {k: cu(v) for k, v in nlidar.synthetic_sweep(width=48, seed=4, beams=nlidar.LIDAR_ANGLES[::2]).items()}
+    outs = []
+    try:
+        for generic in ("0", "1"):
+            os.environ["NLR_ENCODE_GENERIC"] = generic
+            r, h = model.render_rays(batch, compute_extras=True, scale_factor=1 / 250, want_history=True)
+            torch.cuda.synchronize()
+            outs.append((r, h))
+    finally:
+        os.environ.pop("NLR_ENCODE_GENERIC", None)
+    (r0, h0), (r1, h1) = outs
+    for lvl in range(mc.num_levels):
+        for k in ("sdist", "tdist", "density", "weights"):
+            assert torch.equal(h0[lvl][k], h1[lvl][k]), f"level {lvl} {k}: fast and generic level bodies differ"
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+    assert float(h0[-1]["density"].max()) > 1.0
