@@ -107,20 +107,23 @@ def cpu_baseline(mc, sd, batch_np, idx, threads):
     b = {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in batch_np.items()}
     enc = orc.make_encoders(sd, mc)
     sdt = orc.to_torch_sd(sd)
-    chunk = 1024
-    outs = []
+    chunk = 4096  # chunks of 4 096 rays
+    passes = []
     with torch.no_grad():
         orc.model_forward(sd, mc, {k: v[:256] for k, v in b.items()}, encoders=enc, sd_t=sdt)  # warm-up
-        t0 = time.perf_counter()
-        for i in range(0, n_rays, chunk):
-            outs.append(orc.model_forward(sd, mc, {k: v[i:i + chunk] for k, v in b.items()}, encoders=enc, sd_t=sdt)[0][-1])
-        dt = time.perf_counter() - t0
+        for _ in range(3):  # median of 3 passes over the sample (median of 5 over all 32 768 rays = ~150 s; bounded here)
+            outs = []
+            t0 = time.perf_counter()
+            for i in range(0, n_rays, chunk):
+                outs.append(orc.model_forward(sd, mc, {k: v[i:i + chunk] for k, v in b.items()}, encoders=enc, sd_t=sdt)[0][-1])
+            passes.append(time.perf_counter() - t0)
+    dt = sorted(passes)[1]
     ref = {k: torch.cat([o[k] for o in outs]).numpy() for k in ("depth", "intensity", "semantic") if k in outs[0]}
     return dict(value=n_rays / dt, unit="rays/s", cores=threads, kind="port",
-                sample=f"{n_rays} rays of the same sweep (every {len(batch_np['origins']) // n_rays}th ray), "
-                       f"same weights, chunks of {chunk}, ONE pass after a 256-ray warm-up, {dt:.1f} s of wall time, fp32 PyTorch-CPU + "
-                       f"OpenMP C grid oracle (SURVEY 8d asks for all 32 768 rays in chunks of 4 096, median of 5: that is ~150 s of CPU "
-                       f"work, bounded here so that the default run stays within minutes)"), ref
+                sample=f"{n_rays} rays of the same sweep (every {len(batch_np['origins']) // n_rays}th ray), same weights, chunks of {chunk}, "
+                       f"median of 3 passes after a 256-ray warm-up ({', '.join(f'{p_:.1f}' for p_ in passes)} s), fp32 PyTorch-CPU + OpenMP C grid "
+                       f"oracle; SURVEY 8d's protocol (all 32 768 rays, median of 5) is ~150 s of CPU work and is bounded to this sample so that "
+                       f"the default run stays within minutes"), ref
 
 
 def accuracy(ref, r, idx):
