@@ -781,8 +781,25 @@ def gen_train_step():
         g = named[k].grad
         assert g is not None and float(g.abs().sum()) > 0, k
         out["grad_" + k] = g
-    print("   loss terms:", {k: float(v) for k, v in losses.items()}, "total", float(loss))
+    print("   loss terms:", {k: float(v.detach()) for k, v in losses.items()}, "total", float(loss.detach()))
     save("train_step_REF", **out)
+    # The mask logic alone (train.py: from `if config.dataset_loader == 'nusc':` to `batch['mask_rgb'] = rgb_mask`), executed from the
+    # reference's file for every combination of the four switches it reads.
+    m0 = next(i for i, l in enumerate(src) if l.strip().startswith("if config.dataset_loader == 'nusc':"))
+    m1 = next(i for i, l in enumerate(src) if l.strip() == "batch['mask_rgb'] = rgb_mask")
+    mblock = textwrap.dedent("\n".join(src[m0:m1 + 1]))
+    M = 257
+    raw = dict(mask=(rnd(81, 1, (M,)) > 0.6).float(), patch_mask=torch.zeros(M), depth=rnd(81, 2, (M,), -0.2, 1.0), aug_mask=(rnd(81, 5, (M,)) > 0.8).float(),
+               semantic=torch.where(rnd(81, 3, (M,)) > 0.8, torch.full((M,), 255.0), (rnd(81, 4, (M,)) * 19).floor()), lidar_mask=(rnd(81, 6, (M,)) > 0.5).float())
+    mout = {"in_" + k: v for k, v in raw.items()}
+    for code in range(16):
+        lid, only, inst, aug = bool(code & 1), bool(code & 2), bool(code & 4), bool(code & 8)
+        config.lidar_supervision, config.only_lidar_supervison, config.instance_obj, config.aug_road = lid, only, inst, aug
+        bb = {k: v.clone() for k, v in raw.items()}
+        ns2 = dict(torch=torch, config=config, batch=bb)
+        exec(compile(mblock, "train.py[%d:%d]" % (m0 + 1, m1 + 1), "exec"), ns2)
+        mout[f"c{code}_mask_rgb"], mout[f"c{code}_depth_mask"], mout[f"c{code}_sem_mask"] = ns2["rgb_mask"], ns2["depth_mask"], ns2["sem_mask"]
+    save("fn_nusc_masks", train_py_lines=np.array([m0 + 1, m1 + 1]), **mout)
 
 
 if __name__ == "__main__":
