@@ -10,7 +10,10 @@
 //     reduced mod hsize on the scalar unit and multiply pre-shifted coordinates (y, z < 2^14, P mod hsize < 2^24: no overflow into
 //     the kept bits): offset = ((x<<e) ^ (y<<e)*P1' ^ (z<<e)*P2') & ((hsize-1)<<e), e = log2(bytes per entry); the "+1"
 //     corners are adds of (P'<<e); `(a ^ b) & m` is one v_bitop3_b32.  Bit-identical to (x ^ y*P1 ^ z*P2) % hsize;
-//   * dense levels: x<<e + y*(step<<e) + z*(step^2<<e) with v_mul_u32_u24 and one v_add3_u32 per corner;
+//   * dense levels: x<<e + y*(step<<e) + z*(step^2<<e), two multiplies (v_mul_lo_u32: full rate on gfx950, the 24-bit multiply is
+//     the slower one - profiles/r03_valu_rate_microbench.txt) and adds per corner; entries of <= 8 bytes: the x and x+1 corners are
+//     neighbours and come with ONE gather (NlrPair);
+//   * waves whose points all sit in one cell fetch its 8 corners through the scalar cache instead (see "wave-uniform cells" below);
 //   * linear interpolation and align_corners = False are compile-time (the only values the path uses, grid.py:38-39 defaults);
 //   * the sum over the 8 lanes of a multisample group is 3 v_add_f32_dpp per value (inline asm: the compiler pairs the adds into
 //     v_pk_add_f32, which cannot carry a DPP operand, and then needs a v_mov_b32_dpp + a zeroing v_mov per operand).
