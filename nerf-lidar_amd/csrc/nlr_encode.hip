@@ -599,6 +599,9 @@ static bool nlr_force_generic() {
 }
 
 int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, int piece_major, hipStream_t st) {
+    // 8 lanes per sample with a 32-bit lane index (the kernels compute N * S in 32 bits)
+    NLR_CHECK_ARG((uint64_t)cp.N * cp.S * 8 < (1ull << 32), "encode: N * S = %llu samples do not fit the 32-bit lane index (chunk the rays)",
+                  (unsigned long long)cp.N * cp.S);
     const uint32_t M = cp.N * cp.S;
     if (cp.n <= 8) {  // multisample-parallel mapping
         dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
@@ -651,6 +654,8 @@ int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights
 
 int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1, const float *b1, const float *w2, float b2,
                     float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st) {
+    NLR_CHECK_ARG((uint64_t)cp.N * cp.S * 8 < (1ull << 32), "proposal level: N * S = %llu samples do not fit the 32-bit lane index (chunk the rays)",
+                  (unsigned long long)cp.N * cp.S);
     const uint32_t M = cp.N * cp.S;
     PropMlpParams mp;
     mp.w1 = w1;

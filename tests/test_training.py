@@ -541,3 +541,22 @@ def test_fused_encode_features_matches_the_torch_chain(which, rand):
     scale = float(g_ref.abs().max())
     assert scale > 0
     np.testing.assert_allclose(g_got.cpu().numpy(), g_ref.cpu().numpy(), rtol=0, atol=2e-5 * scale)
+
+
+@pytest.mark.gpu
+def test_encode_kernels_refuse_a_sample_count_beyond_their_lane_index():
+    """8 lanes per sample with a 32-bit lane index: N * S >= 2^29 samples is an enumerated error (NLR_ERR_INVALID with a message), not a
+    wrapped grid.  Nothing is launched: the tensors handed in are far smaller than the claimed shape."""
+    import ctypes as C
+    from nerflidar_hip import _lib
+    from nerflidar_hip.gridencoder import GridEncoder
+    mc, sd, batch = _ref_scene(log2_hashmap=12, width=8)
+    enc = GridEncoder(input_dim=3, num_levels=6, level_dim=1, base_resolution=16, desired_resolution=512, log2_hashmap_size=12).cuda()
+    n = batch["origins"].shape[0]
+    from nerflidar_hip.models import _RAY_KEYS
+    keep = [batch[k].reshape(n, -1).contiguous().float() for k in _RAY_KEYS]
+    rays, gd = ntrain._EncodeFeatures._descs(enc, keep, enc.embeddings.detach().contiguous())
+    td = torch.zeros(64, device="cuda")
+    out = torch.zeros(64, device="cuda")
+    rc = _lib.lib().nlr_encode_features_forward(C.byref(rays), _lib.ptr(td), 1 << 23, 64, 7, 3, 0.35, None, C.byref(gd), 1, _lib.ptr(out), None)
+    assert rc == -1 and b"32-bit lane index" in _lib.lib().nlr_last_error()
