@@ -135,6 +135,8 @@ def workload(name: str, log2_hashmap: Optional[int] = None) -> ModelConfig:
     """REF = shipped gin; C1 = 4x128, 64 samples, single level; C2 = 8x256, (64,64,128)+intensity."""
     if name == "REF":
         mc = ModelConfig()
+    elif name == "REFI":  # the shipped architecture with the intensity head switched on (Config.use_intensity, configs.py:164)
+        mc = ModelConfig(config=Config(use_intensity=True))
     elif name == "C1":
         mc = ModelConfig(num_prop_samples=(), num_nerf_samples=64, num_levels=1,
                          nerf_mlp=MLPConfig(net_depth_viewdirs=4, net_width_viewdirs=128))

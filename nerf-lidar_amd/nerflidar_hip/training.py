@@ -632,6 +632,23 @@ def clip_gradients(model: torch.nn.Module, grad_max_norm: float = 0.0, grad_max_
             p.grad.nan_to_num_()
 
 
+def learning_rate_decay(step: int, lr_init: float = 0.01, lr_final: float = 0.001, max_steps: int = 25000, lr_delay_steps: int = 5000,
+                        lr_delay_mult: float = 1e-8) -> float:
+    """ZI/math.py:54-85 with the defaults of ZI/configs.py:85-88: log-linear decay from lr_init to lr_final over max_steps, eased in
+    over lr_delay_steps by `mult + (1 - mult) sin(pi/2 * step / delay)`."""
+    delay = lr_delay_mult + (1 - lr_delay_mult) * float(np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))) if lr_delay_steps > 0 else 1.0
+    t = float(np.clip(step / max_steps, 0, 1))
+    return delay * float(np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
+
+
+def create_optimizer(model: torch.nn.Module, lr_init: float = 0.01, lr_final: float = 0.001, max_steps: int = 25000, lr_delay_steps: int = 5000,
+                     lr_delay_mult: float = 1e-8, adam_beta1: float = 0.9, adam_beta2: float = 0.99, adam_eps: float = 1e-15):
+    """train_utils.py:256-275: Adam(betas = (0.9, 0.99), eps = 1e-15) over all parameters and the learning-rate function the loop
+    writes into every param_group before each step (train.py:187-190).  Returns (optimizer, lr_fn)."""
+    opt = torch.optim.Adam(model.parameters(), lr=lr_init, betas=(adam_beta1, adam_beta2), eps=adam_eps)
+    return opt, (lambda step: learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps, lr_delay_mult))
+
+
 def training_step(model: TrainableModel, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], train_frac: float = 1.0,
                   randomized: bool = True, hash_decay_mult: float = 0.1, tv_weight: float = 0.0, grad_max_norm: float = 0.0,
                   grad_max_val: float = 0.0, **loss_kw) -> Dict[str, float]:

@@ -666,6 +666,48 @@ def gen_losses():
     save("fn_losses", **out)
 
 
+def gen_trained():
+    """a TRAINED, well-conditioned scene through the reference.  `tests/golden/ckpt_trained/checkpoint_<step>.ckpt`
+    was written on the GPU box by `python -m nerflidar_hip.train_scene` (`training.training_step` on the analytic scene of
+    nerflidar_hip/scene.py, saved by `checkpoints.save_checkpoint` in the reference's format; `train_summary.json` beside it is that
+    run's log).  Here the REFERENCE restores it - `internal/checkpoints.restore_checkpoint` into the reference `Model`
+    (render_lidar.py:74) - and renders rays of a held-out sweep (a sensor position no training ray started from) with
+    `Model.forward`; stored: inputs, the reference's outputs for every ray, per-sample history of the first rays."""
+    print("trained-scene fixture (reference restore_checkpoint + Model.forward)")
+    import glob
+    import json
+    ck_dir = os.path.join(HERE, "ckpt_trained")
+    summ = json.load(open(os.path.join(ck_dir, "train_summary.json")))["summary"]
+    wl, lg = summ["workload"], summ["log2_hashmap"]
+    mc = nconfig.workload(wl, lg)
+    model = build_ref_model(mc, nweights.synth_state_dict(mc, seed=0, trained_like=False))   # placeholder weights, replaced next
+    step = rcheckpoints.restore_checkpoint(ck_dir, model)
+    assert step == summ["steps"], (step, summ["steps"])
+    model.eval()
+    sweep_idx, width, every = 100, 1024, 40
+    full = nlidar.synthetic_sweep(width=width, seed=0, sweep_idx=sweep_idx)   # viewdirs carry the whole sweep's Frobenius norm
+    idx = np.arange(0, full["origins"].shape[0], every)
+    batch_np = {k: np.ascontiguousarray(v[idx]) for k, v in full.items()}
+    batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    with torch.no_grad():
+        rend, hist = model(False, batch, train_frac=1.0, compute_extras=True, zero_glo=True)
+    out = {"out_" + k: v for k, v in rend[-1].items() if not k.startswith("ray_")}
+    K = 24
+    for lvl, h in enumerate(hist):
+        for k in ("sdist", "weights", "tdist", "density", "rgb", "semantic", "intensity"):
+            if h.get(k) is not None and not (k == "rgb" and lvl < len(hist) - 1):
+                out[f"hist{lvl}_{k}"] = h[k][:K]
+        out[f"lvl{lvl}_depth"] = rend[lvl]["depth"]
+    # how concentrated the trained field is (the white-noise fixtures spread their weight over many samples)
+    w = hist[-1]["weights"]
+    print(f"   {len(idx)} rays; max weight per ray: median {float(w.max(-1).values.median()):.3f}; depth {float(rend[-1]['depth'].min()):.4f}.."
+          f"{float(rend[-1]['depth'].max()):.4f}; labels {sorted(set(rend[-1]['semantic'].argmax(-1).tolist()))}")
+    save(f"fwd_TRAINED_{wl}", workload=np.array(wl), log2_hashmap=np.array(lg), ckpt_step=np.array(step), sweep_idx=np.array(sweep_idx),
+         width=np.array(width), ray_index=idx, **{"in_" + k: v for k, v in batch_np.items()
+                                                 if k in ("origins", "directions", "viewdirs", "radii", "near", "far")}, **out)
+
+
+
 class _RefGridFn(torch.autograd.Function):
     """Autograd through the CPU restatement of the grid kernels (forward cu:87-199, backward cu:248-340) for the reference import in
     training mode: gradients reach the embeddings (positions carry none: Model.stop_level_grad)."""
@@ -817,6 +859,9 @@ if __name__ == "__main__":
     if os.environ.get("NLR_GOLDEN_ONLY") == "train_step":
         gen_train_step()
         raise SystemExit(0)
+    if os.environ.get("NLR_GOLDEN_ONLY") == "trained":
+        gen_trained()
+        raise SystemExit(0)
     if os.environ.get("NLR_GOLDEN_ONLY") == "f4":
         gen_raydrop_apply()
         gen_checkpoint()
@@ -837,4 +882,5 @@ if __name__ == "__main__":
     gen_checkpoint()
     gen_losses()
     gen_train_step()
+    gen_trained()
     print("done")
