@@ -29,6 +29,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 H_BEAMS, W_COLS = 32, 1024
+PMC_PROFILE = "r04_pmc_traffic.json"  # scripts/pmc_traffic.sh on the final binary of the round
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 KNAMES = ["resample", "prop", "encode", "direnc", "mlp", "composite"]
 
@@ -57,6 +58,18 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true", help="replay the sweep from a HIP graph (models.CapturedRender), one graph per tile buffer: "
                     "one graph launch per step instead of ~10 kernel launches; the per-kernel HIP events are not part of a captured "
                     "sweep, so kernel_ms / roofline are not reported in this mode")
+    ap.add_argument("--ckpt", default=None, help="render a TRAINED checkpoint (reference format, nerflidar_hip.checkpoints) instead of the seeded "
+                    "synthetic weights; the architecture comes from the file, sampling counts from --workload (or the train_summary.json "
+                    "`python -m nerflidar_hip.train_scene` leaves beside it)")
+    ap.add_argument("--inflate-log2", type=int, default=None, help="with --ckpt: re-lay the checkpoint's hash maps out at 2^N rows per hashed "
+                    "level (nerflidar_hip.weights.inflate_hashmaps: the same field bit for bit, with the footprint and the access pattern "
+                    "of the larger maps; 21 = the full-size configuration)")
+    ap.add_argument("--no-trained-leg", action="store_true", help="skip the `trained_scene` object (the default one-GPU run also renders "
+                    "the committed trained checkpoint, inflated to full-size maps, for a second, scene-shaped measurement)")
+    ap.add_argument("--static-origin", action="store_true", help="render the SAME sweep every step (round 1-3 behaviour).  Default: step i "
+                    "renders synthetic_sweep(sweep_idx = i mod 64) from pre-uploaded ray batches, as a LiDAR replay moves the sensor every "
+                    "sweep (Z/train.py:484-485 counts rays of distinct batches), so the caches hold what a replay leaves, not the "
+                    "previous step's identical access pattern")
     ap.add_argument("--selftest-cpu", action="store_true", help="launcher + partition + collective logic on CPU (gloo) with a "
                     "stand-in renderer; for tests/, measures nothing")
     ap.add_argument("--selftest-hw", type=int, nargs=2, default=[4, 64], metavar=("H", "W"),
@@ -95,7 +108,7 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(mc, sd, batch_np, idx, threads):
+def cpu_baseline(mc, sd, batch_np, idx, threads, passes=3):
     """The oracle (a port: PyTorch-CPU restatement pinned on reference fixtures) timed on this host's cores.  Returns the
     cpu_baseline object and the oracle's renderings of the sampled rays (for `accuracy`)."""
     import numpy as np
@@ -108,16 +121,16 @@ def cpu_baseline(mc, sd, batch_np, idx, threads):
     enc = orc.make_encoders(sd, mc)
     sdt = orc.to_torch_sd(sd)
     chunk = 4096  # chunks of 4 096 rays
-    passes = []
+    n_pass, passes = passes, []
     with torch.no_grad():
         orc.model_forward(sd, mc, {k: v[:256] for k, v in b.items()}, encoders=enc, sd_t=sdt)  # warm-up
-        for _ in range(3):  # median of 3 passes over the sample (median of 5 over all 32 768 rays = ~150 s; bounded here)
+        for _ in range(n_pass):  # median of 3 passes over the sample (median of 5 over all 32 768 rays = ~150 s; bounded here)
             outs = []
             t0 = time.perf_counter()
             for i in range(0, n_rays, chunk):
                 outs.append(orc.model_forward(sd, mc, {k: v[i:i + chunk] for k, v in b.items()}, encoders=enc, sd_t=sdt)[0][-1])
             passes.append(time.perf_counter() - t0)
-    dt = sorted(passes)[1]
+    dt = sorted(passes)[len(passes) // 2]
     ref = {k: torch.cat([o[k] for o in outs]).numpy() for k in ("depth", "intensity", "semantic") if k in outs[0]}
     return dict(value=n_rays / dt, unit="rays/s", cores=threads, kind="port",
                 sample=f"{n_rays} rays of the same sweep (every {len(batch_np['origins']) // n_rays}th ray), same weights, chunks of {chunk}, "
@@ -144,6 +157,83 @@ def accuracy(ref, r, idx):
         out["label_mismatches"] = int((g["labels"] != ref["semantic"].argmax(-1)).sum())
         out["min_top2_margin"] = float((sr[:, -1] - sr[:, -2]).min())
     return out
+
+
+TRAINED_CKPT = os.path.join(ROOT, "tests", "golden", "ckpt_trained_c2")
+
+
+def trained_scene_leg(dev, precision, threads, steps=20, warmup=5, oracle_rays=2048):
+    """Second measurement of the default one-GPU run: the SAME configuration (C2: (64, 64, 128) samples, 8x256 NerfMLP + semantic +
+    intensity heads, full-size fp32 maps, one 32 x 1024 sweep per step, moving origin) on a TRAINED field instead of seeded white noise.
+    The committed checkpoint (tests/golden/ckpt_trained_c2: `python -m nerflidar_hip.train_scene` on the analytic street scene, small
+    hash maps so that it fits the repository) is re-laid out on 2^21-row maps by `weights.inflate_hashmaps` - the same function value
+    for value, with the 229 MiB footprint and the scattered fine-level accesses of the full-size configuration.  Samples follow the
+    scene's surfaces, so the gather kernels see the line traffic of a real replay (the white-noise scene terminates every ray within
+    a few cells of the sensor: cache-friendly far beyond any real scene).  Returns the `trained_scene` object, or None without the file."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from nerflidar_hip import _lib, checkpoints as nckpt, config as nconfig, flops as nflops, lidar as nlidar, weights as nweights
+    from nerflidar_hip.models import Model
+    if not os.path.isdir(TRAINED_CKPT):
+        return None
+    summ = json.load(open(os.path.join(TRAINED_CKPT, "train_summary.json")))["summary"]
+    sd_all, ck_step = nckpt.load_checkpoint(TRAINED_CKPT)
+    sd, _ = nckpt.split_state_dict(sd_all)
+    mc = nckpt.infer_model_config(sd, nconfig.workload(summ["workload"], summ["log2_hashmap"]))
+    for prefix, cfg_ in nweights.mlp_names(mc):
+        sd[f"{prefix}.encoder.offsets"], sd[f"{prefix}.encoder.grid_sizes"], _ = nweights.grid_layout(cfg_)
+    sd, mc = nweights.inflate_hashmaps(sd, mc, 21)
+    model = Model(mc, sd, device=dev, precision=precision)
+    n_sw = 32
+    secs = [nlidar.synthetic_sweep(width=W_COLS, seed=0, sweep_idx=100 + si) for si in range(n_sw)]  # sensor positions no training ray used
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in secs[0].items()}
+    origins = [torch.from_numpy(np.ascontiguousarray(s_["origins"])).to(dev) for s_ in secs]
+    n_rays = batch["origins"].shape[0]
+    tile = torch.zeros(W_COLS, H_BEAMS, 7, device=dev)
+    sf = 1.0 / 250.0
+    L = _lib.lib()
+
+    def step(i):
+        batch["origins"] = origins[i % n_sw]
+        return model.render_rays(batch, compute_extras=True, scale_factor=sf, packed=tile)[0]
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    _lib.check(L.nlr_profile_begin_kinds(model._handle, (1 << 4) | (1 << 2)), "nlr_profile_begin_kinds")
+    t0 = time.perf_counter()
+    for i in range(steps):
+        r = step(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = (C.c_float * _lib.NLR_K_COUNT)()
+    cnt = (C.c_uint32 * _lib.NLR_K_COUNT)()
+    _lib.check(L.nlr_profile_end(model._handle, _lib.current_stream(), ms, cnt), "nlr_profile_end")
+    ms2 = (C.c_float * _lib.NLR_K_COUNT)()
+    cnt2 = (C.c_uint32 * _lib.NLR_K_COUNT)()
+    _lib.check(L.nlr_profile_begin(model._handle), "nlr_profile_begin")
+    for i in range(4):
+        step(warmup + steps + i)
+    torch.cuda.synchronize()
+    _lib.check(L.nlr_profile_end(model._handle, _lib.current_stream(), ms2, cnt2), "nlr_profile_end")
+    kern = {}
+    for k_ in range(_lib.NLR_K_COUNT):
+        m_, c_ = (ms[k_], cnt[k_]) if k_ in (2, 4) else (ms2[k_], cnt2[k_])
+        kern[KNAMES[k_]] = round(m_ / c_, 4) if c_ else 0.0
+    last = (warmup + steps - 1) % n_sw
+    r = step(last)            # the sweep the accuracy leg checks (the 4 untimed sweeps above moved on)
+    torch.cuda.synchronize()
+    fl = 2.0 * nflops.macs_per_sample(mc.nerf_mlp) * n_rays * mc.level_samples()[-1]
+    idx = np.linspace(0, n_rays - 1, oracle_rays).astype(np.int64)
+    _, ref = cpu_baseline(mc, sd, secs[last], idx, threads, passes=1)
+    return {"value": n_rays * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "kernel_ms": kern, "mlp_roofline_frac": (fl / (kern["mlp"] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS) if kern["mlp"] else None,
+            "accuracy": accuracy(ref, r, idx),
+            "workload": f"C2 architecture and sampling on the trained analytic street scene: checkpoint step {ck_step} "
+                        f"({os.path.relpath(TRAINED_CKPT, ROOT)}, trained with 2^{summ['log2_hashmap']}-row maps), hash maps inflated to 2^21 rows "
+                        "(same field, full-size footprint), held-out sensor positions, moving origin",
+            "scene_fit": summ.get("held_out_sweep")}
 
 
 def pmc_traffic(profile_path, binary_sha, sources_sha, kernel, applicable=True):
@@ -231,15 +321,42 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
-    mc = nconfig.workload(args.workload, args.log2_hashmap)
-    sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
-    model = Model(mc, sd, device=dev, precision=args.precision,
-                  table_dtype=torch.float16 if args.table_dtype == "f16" else torch.float32)
+    tdt = torch.float16 if args.table_dtype == "f16" else torch.float32
+    ckpt_note = None
+    if args.ckpt:
+        from nerflidar_hip import checkpoints as nckpt
+        wl, lg = args.workload, args.log2_hashmap
+        summ_path = os.path.join(args.ckpt if os.path.isdir(args.ckpt) else os.path.dirname(args.ckpt), "train_summary.json")
+        if os.path.exists(summ_path):
+            summ = json.load(open(summ_path))["summary"]
+            wl, lg = summ["workload"], summ["log2_hashmap"]
+            ckpt_note = {k: summ[k] for k in ("workload", "log2_hashmap", "steps", "rays_per_step", "held_out_sweep") if k in summ}
+        args.workload = wl
+        sd_all, ck_step = nckpt.load_checkpoint(args.ckpt)
+        sd, _ignored = nckpt.split_state_dict(sd_all)
+        mc = nckpt.infer_model_config(sd, nconfig.workload(wl, lg))
+        for prefix, cfg_ in nweights.mlp_names(mc):  # buffers the oracle reads (re-derived from the config, grid.py:137-142)
+            sd[f"{prefix}.encoder.offsets"], sd[f"{prefix}.encoder.grid_sizes"], _ = nweights.grid_layout(cfg_)
+        ckpt_note = dict(ckpt_note or {}, path=os.path.relpath(args.ckpt, ROOT), restored_step=ck_step)
+        if args.inflate_log2:
+            sd, mc = nweights.inflate_hashmaps(sd, mc, args.inflate_log2)
+            ckpt_note["hash_maps_inflated_to_log2"] = args.inflate_log2
+            lg = args.inflate_log2
+        args.log2_hashmap = None if lg in (None, 21) else lg
+    else:
+        mc = nconfig.workload(args.workload, args.log2_hashmap)
+        sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
+    model = Model(mc, sd, device=dev, precision=args.precision, table_dtype=tdt)
     width = args.width * (world if args.scaling == "weak" else 1)
-    full = nlidar.synthetic_sweep(width=width, seed=0)
     emul = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
-    sec, wp = nlidar.azimuth_sector(full, H_BEAMS, width, rank, emul or world)
-    batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in sec.items()}
+    n_sweeps = 1 if args.static_origin else 64
+    secs = []
+    for si in range(n_sweeps):  # the sweeps of a replay differ in the sensor position only (lidar.synthetic_sweep: origin = o0(sweep_idx))
+        full = nlidar.synthetic_sweep(width=width, seed=0, sweep_idx=si)
+        sec, wp = nlidar.azimuth_sector(full, H_BEAMS, width, rank, emul or world)
+        secs.append(sec)
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in secs[0].items()}
+    origins = [torch.from_numpy(np.ascontiguousarray(s_["origins"])).to(dev) for s_ in secs]  # pre-uploaded: resident when the timed region starts
     n_rays = H_BEAMS * wp
     sf = 1.0 / 250.0
     if emul:
@@ -256,11 +373,15 @@ def main():
             caps[b_] = CapturedRender(model, batch, compute_extras=True, scale_factor=sf, want_history=args.history, packed=gat.tiles[b_])
 
     def step(i):
-        tile = gat.tile(i)
+        tile = gat.tile(i if gat.collective else 0)  # without a collective nothing reads the tile behind the render: one buffer
+        last["sweep"] = i % n_sweeps
         if caps:
+            if n_sweeps > 1:
+                batch["origins"].copy_(origins[i % n_sweeps])  # a captured sweep reads its static input buffers: refill in place
             last["r"] = caps[(i & 1) if len(caps) == 2 else 0].replay()
             gat.submit(i)
             return
+        batch["origins"] = origins[i % n_sweeps]
         if args.chunk and args.chunk < n_rays:  # chunked like the reference's driver; records land in ray order
             flat = torch.empty(n_rays, 7, device=dev)
             for a in range(0, n_rays, args.chunk):
@@ -290,7 +411,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    img = gat.image(args.warmup + args.steps - 1)
+    img = gat.image((args.warmup + args.steps - 1) if gat.collective else 0)
     barrier()
     dt = time.perf_counter() - t0
     ms = (C.c_float * _lib.NLR_K_COUNT)()
@@ -343,20 +464,41 @@ def main():
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh), which record the source hash
         # COMPILED INTO the binary they measured: a profile of other code is not a measurement of this binary.
         bsha, ssha = buildinfo.binary_sha(), buildinfo.kernel_source_sha()
-        prof = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        prof = os.path.join(ROOT, "profiles", PMC_PROFILE)
         plain = (world == 1 and args.workload == "C2" and not args.chunk and not emul and args.width == W_COLS and args.table_dtype == "f32"
-                 and args.precision == 2 and args.log2_hashmap is None)
+                 and args.precision == 2 and args.log2_hashmap is None and not args.ckpt and not args.static_origin)
         traffic, tnote = pmc_traffic(prof, bsha, ssha, "nlr_mlp_kernel", plain)
-        g_traffic, g_note = pmc_traffic(prof, bsha, ssha, "nlr_encode8_kernel", plain)
-        # second ceiling: the gather side.  Algorithmic bytes of nlr_encode8_kernel per launch = samples x 7 multisamples x
-        # L levels x 8 corners x C channels x bytes; its ceiling is the vector L1's look-up rate (one 64-byte quad access per clock and
-        # CU), priced here as 64 B x 256 CUs x 2.4 GHz.
+        # second ceiling: the gather side, priced in bytes that really cross the L2's memory-side port.  achieved = PMC counter
+        # bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section; the committed profile of THIS binary) / the
+        # kernel's launch duration measured here with HIP events; peak = 8 TB/s HBM (the guide's measured random-gather rates from tables
+        # in the Infinity Cache are 7.4-8.6 TB/s, streamed HBM 6.0-6.3 TB/s).  The algorithmic gather bytes (samples x 7 multisamples x L
+        # levels x 8 corners x C channels x 4 B) are kept as a note: most of them are served by the scalar cache, by lanes sharing a
+        # look-up and by L1/L2 hits, so their rate is not a roofline fraction.
         ncfg = mc.nerf_mlp
         tb = 4 if args.table_dtype == "f32" else 2
         g_bytes = float(launch_rays) * S_last * 7 * ncfg.grid_num_levels * 8 * ncfg.grid_level_dim * tb
-        enc_s = kern["encode"] * 1e-3
-        g_ach = g_bytes / enc_s / 1e9 if enc_s > 0 else 0.0
-        L1_PEAK_GBS = 64.0 * 256 * 2.4
+        HBM_PEAK_GBS = 8000.0
+
+        def gather_roofline(kernel, key, alg_bytes, launches_per_step):
+            t_s = kern[key] * 1e-3
+            tr, note = pmc_traffic(prof, bsha, ssha, kernel, plain)
+            ach = (tr / t_s / 1e9) if (tr is not None and t_s > 0) else None
+            return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": tr, "traffic_note": note,
+                    "launch_ms": round(kern[key], 4), "launches_per_step": launches_per_step,
+                    "algorithmic_gather_bytes": alg_bytes, "algorithmic_gather_GBps": (alg_bytes / t_s / 1e9) if t_s > 0 else None,
+                    "note": "achieved = PMC bytes past L2 per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, Infinity-Cache hits "
+                            "included: the counter sits on the L2's fabric side) / HIP-event launch duration, against 8 TB/s; the guide's "
+                            "random-gather ceilings are 7.4-8.6 TB/s (tables in the Infinity Cache) and ~6 TB/s (HBM stream).  "
+                            "algorithmic_gather_* counts every corner read of every multisample and is NOT a roofline figure (scalar-cache "
+                            "path, shared look-ups, L1/L2 hits)"}
+
+        samples = mc.level_samples()
+        props = [mc.prop_cfg(i) for i in range(mc.num_levels - 1)]
+        p_bytes = (sum(float(launch_rays) * samples[i] * 7 * c_.grid_num_levels * 8 * c_.grid_level_dim * tb for i, c_ in enumerate(props)) / len(props)
+                   if props else 0.0)
+        rg = gather_roofline("nlr_encode8_kernel", "encode", g_bytes, 1)
+        rp = gather_roofline("nlr_prop8_kernel", "prop", p_bytes, len(props)) if props else None
         out = {
             "metric": "LiDAR rays/sec @128 samples/ray, 8x256 MLP; depth L1 vs reference",
             "value": rays_total / dt,
@@ -381,19 +523,25 @@ def main():
                        "rays_per_gpu_per_step": n_rays, "azimuth_columns_total": width,
                        "parallelism": f"azimuth-sector x{world}" + (" + 1 all_gather of the packed range image on a side stream" if use_dist else ""),
                        "per_sample_history": bool(args.history), "hip_graph_replay": bool(caps),
+                       "weights": ("trained checkpoint" if args.ckpt else "seeded synthetic (white-noise tables, x1500 density gain)"),
+                       "sweep_origins": ("static: the same sweep every step" if args.static_origin else
+                                         f"moving: step i renders sweep i mod {n_sweeps} (pre-uploaded ray batches)"),
                        "flops_per_ray": nflops.flops_per_ray(mc), "gather_bytes_per_ray": nflops.gather_bytes_per_ray(mc)},
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "roofline": {"kernel": "nlr_mlp_kernel", "bound": "mfma", "achieved": achieved,
                          "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote},
-            "roofline_gather": {"kernel": "nlr_encode8_kernel", "bound": "l1-lookup", "achieved": g_ach, "peak": L1_PEAK_GBS, "unit": "GB/s",
-                                "frac": g_ach / L1_PEAK_GBS, "algorithmic_bytes": g_bytes, "traffic": g_traffic, "traffic_note": g_note,
-                                "note": "achieved = algorithmic gather bytes / launch duration; peak = 64 B per clock per CU of vector-L1 return "
-                                        "(256 CUs x 2.4 GHz); wave-uniform cells are fetched through the scalar cache and multisamples in one cell "
-                                        "share a look-up, so the algorithmic rate may exceed the L1 ceiling"},
+            "roofline_gather": rg,
+            "roofline_prop": rp,
             "kernel_source_sha": bsha[:16],
             "binary_stale": buildinfo.stale(),
         }
+        if ckpt_note:
+            out["config"]["checkpoint"] = ckpt_note
+        if caps:  # a captured sweep carries no per-kernel HIP events: nothing to report, rather than zeros
+            out["kernel_ms"] = None
+            out["roofline"].update(achieved=None, frac=None, traffic=None, traffic_note="HIP-graph replay: per-kernel durations are not measured in this mode")
+            out["roofline_gather"] = out["roofline_prop"] = None
         if emul:  # not a benchmark result: what ONE rank of an `emul`-way split does per step, measured on one GPU
             out["emulated_world"] = emul
             out["metric"] = f"DIAGNOSTIC per-rank step of a {emul}-way azimuth split (one GPU, no collective)"
@@ -408,8 +556,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline and "r" in last:
             threads = host_cores()
             idx = np.linspace(0, n_rays - 1, args.cpu_rays).astype(np.int64)
-            out["cpu_baseline"], ref = cpu_baseline(mc, sd, sec, idx, threads)
+            out["cpu_baseline"], ref = cpu_baseline(mc, sd, secs[last["sweep"]], idx, threads)  # the sweep the last step rendered
             out["accuracy"] = accuracy(ref, last["r"], idx)
+            if plain and not args.no_trained_leg:
+                del model, last["r"]
+                torch.cuda.empty_cache()
+                out["trained_scene"] = trained_scene_leg(dev, args.precision, threads)
         print(json.dumps(out))
     if use_dist:
         torch.distributed.barrier()

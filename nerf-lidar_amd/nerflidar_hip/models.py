@@ -297,17 +297,25 @@ class CapturedRender:
     A LiDAR simulator renders sweep after sweep from ray buffers it refills in place, so the launch sequence never changes; replaying
     it costs one graph launch instead of ~10 kernel launches plus their argument marshalling (at 8 azimuth sectors a rank's step is
     ~1 ms of GPU work against ~0.3 ms of host enqueue).  The ray batch, the optional `packed` tile and the returned output
-    tensors are the buffers of the captured call: refill the inputs in place, `replay()`, read `out` / `hist`."""
+    tensors are the buffers of the captured call: refill the inputs in place, `replay()`, read `out` / `hist`.
+
+    The captured launches carry the raw address of the workspace arena (per-level intermediates).  The capture therefore OWNS that
+    arena: it is allocated for this capture, kept alive by it, and detached from the model, so that a later eager `render_rays` -
+    larger, or on another stream - allocates and uses its own arena instead of freeing or racing the one the graph writes.  Replays of
+    ONE capture must still be ordered with respect to each other (same stream, or events), like any kernel sequence over fixed buffers."""
 
     def __init__(self, model: "Model", batch: Dict[str, torch.Tensor], **kw):
         self.model, self.batch = model, batch
         side = torch.cuda.Stream(model.device)
         self.graph = torch.cuda.CUDAGraph()
+        model._ws = None                     # a private arena for this capture (the model's previous one is released)
         with torch.cuda.stream(side):
             model.render_rays(batch, **kw)  # sizes the workspace outside the capture
             side.synchronize()
             with torch.cuda.graph(self.graph, stream=side):
                 self.out, self.hist = model.render_rays(batch, **kw)
+        self._ws = model._ws                 # the address baked into the graph: alive as long as the capture is
+        model._ws = None                     # eager calls get their own
         torch.cuda.current_stream(model.device).wait_stream(side)
 
     def replay(self):

@@ -94,19 +94,23 @@ def cast(origins: torch.Tensor, directions: torch.Tensor, rotation=None, scale_f
         nrm = torch.zeros(3, dtype=torch.float64, device=dev)
         nrm[axis] = -np.sign(pos)
         take(t, cls, nrm.expand(n, 3))
-    # boxes: slab test
-    for c, s, cls in _BOXES:
-        c = torch.tensor(c, dtype=torch.float64, device=dev)
-        h = torch.tensor(s, dtype=torch.float64, device=dev) / 2
-        inv = 1.0 / safe(d)
-        t0, t1 = (c - h - o) * inv, (c + h - o) * inv
-        tmin, tmax = torch.minimum(t0, t1), torch.maximum(t0, t1)
-        tn, ax = tmin.max(dim=1)
-        tf = tmax.min(dim=1).values
-        hit = (tn < tf) & (tn > 1e-6)
-        nrm = torch.zeros(n, 3, dtype=torch.float64, device=dev)
-        nrm.scatter_(1, ax[:, None], -torch.sign(torch.gather(d, 1, ax[:, None])))
-        take(torch.where(hit, tn, inf), cls, nrm)
+    # boxes: slab test, all boxes at once ([N, B, 3])
+    key = str(dev)
+    if key not in _BOX_T:
+        _BOX_T[key] = (torch.tensor([b[0] for b in _BOXES], dtype=torch.float64, device=dev),
+                       torch.tensor([b[1] for b in _BOXES], dtype=torch.float64, device=dev) / 2,
+                       torch.tensor([b[2] for b in _BOXES], dtype=torch.int64, device=dev))
+    bc, bh, bcls = _BOX_T[key]
+    inv = (1.0 / safe(d))[:, None, :]
+    t0, t1 = (bc - bh - o[:, None, :]) * inv, (bc + bh - o[:, None, :]) * inv
+    tn, ax = torch.minimum(t0, t1).max(dim=2)                       # entry parameter and the axis of the face entered
+    tf = torch.maximum(t0, t1).min(dim=2).values
+    tn = torch.where((tn < tf) & (tn > 1e-6), tn, inf[:, None])
+    tb, ib = tn.min(dim=1)                                           # nearest box per ray
+    axb = torch.gather(ax, 1, ib[:, None])
+    nrm = torch.zeros(n, 3, dtype=torch.float64, device=dev)
+    nrm.scatter_(1, axb, -torch.sign(torch.gather(d, 1, axb)))
+    take(tb, bcls[ib], nrm)
     assert bool((best_cls >= 0).all()), "the scene is closed: every ray must hit something"
     refl, alb = _tables(dev)
     cosi = (-(d / d.norm(dim=-1, keepdim=True)) * best_n).sum(-1).clamp(0.0, 1.0)
@@ -115,26 +119,35 @@ def cast(origins: torch.Tensor, directions: torch.Tensor, rotation=None, scale_f
     return dict(depth=(best_t * scale_factor).float(), semantic=best_cls, intensity=refl[best_cls] * shade, rgb=alb[best_cls] * shade[:, None], normal=best_n.float())
 
 
-_POSITIONS: Dict[tuple, torch.Tensor] = {}
+_POSITIONS: Dict[tuple, tuple] = {}
+_BOX_T: Dict[str, tuple] = {}
 
 
 def random_lidar_rays(n: int, seed: int, step: int, device, rot_seed: int = 0, scale_factor: float = 1.0 / 250.0,
                       origin_range: float = 0.01) -> Dict[str, torch.Tensor]:
-    """A training batch of `n` LiDAR rays with the batch contract of `lidar.cast_lidar_ray_batch` (ZI/lidar_utils.py:8-33): origins
-    drawn like the sweep origins of `lidar.synthetic_sweep` (one of 64 sensor positions per ray), beams from the nuScenes table,
-    azimuths uniform.  Deterministic in (seed, step)."""
-    g = torch.Generator(device="cpu").manual_seed(seed * 1000003 + step)
-    key = (rot_seed, origin_range)
-    if key not in _POSITIONS:  # `lidar.synthetic_sweep(sweep_idx = 0..63)` starts from exactly these
-        _POSITIONS[key] = torch.from_numpy(np.stack([synth.uniform(rot_seed, 9100 + i, (3,), -origin_range, origin_range) for i in range(64)])).double()
-    pos = _POSITIONS[key]
-    o = pos[torch.randint(0, 64, (n,), generator=g)]
-    th = torch.tensor(nlidar.LIDAR_ANGLES, dtype=torch.float64)[torch.randint(0, 32, (n,), generator=g)] / 180 * np.pi
-    ph = torch.rand(n, generator=g, dtype=torch.float64) * 2 * np.pi
-    d = torch.stack([torch.cos(th) * torch.sin(ph), torch.cos(th) * torch.cos(ph), torch.sin(th)], -1)
-    d = (d.float().double() @ torch.from_numpy(nlidar.seeded_rotation(rot_seed)).T)
-    b = nlidar.cast_lidar_ray_batch(o.numpy(), d.numpy(), 2.0 * scale_factor, 500.0 * scale_factor)
-    return {k: torch.from_numpy(v).to(device) for k, v in b.items()}
+    """A training batch of `n` LiDAR rays with the batch contract of `lidar.cast_lidar_ray_batch` (ZI/lidar_utils.py:8-33, incl. the
+    Frobenius-norm `viewdirs` and `base_x = base_y = directions`): origins drawn from the sensor positions of
+    `lidar.synthetic_sweep(sweep_idx = 0..63)`, beams from the nuScenes table, azimuths uniform.  Built on `device` (a few small
+    kernels; on the host the same arithmetic costs more than the training step).  Deterministic in (seed, step) per device type."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed * 1000003 + step)
+    key = (rot_seed, origin_range, str(dev))
+    if key not in _POSITIONS:
+        pos = np.stack([synth.uniform(rot_seed, 9100 + i, (3,), -origin_range, origin_range) for i in range(64)]).astype(np.float64)
+        _POSITIONS[key] = (torch.from_numpy(pos).to(dev), torch.tensor(nlidar.LIDAR_ANGLES, dtype=torch.float64, device=dev) / 180 * np.pi,
+                           torch.from_numpy(nlidar.seeded_rotation(rot_seed)).to(dev))
+    pos, beams, R = _POSITIONS[key]
+    o = pos[torch.randint(0, 64, (n,), generator=g, device=dev)]
+    th = beams[torch.randint(0, 32, (n,), generator=g, device=dev)]
+    ph = torch.rand(n, generator=g, dtype=torch.float64, device=dev) * 2 * np.pi
+    d = torch.stack([torch.cos(th) * torch.sin(ph), torch.cos(th) * torch.cos(ph), torch.sin(th)], -1).float().double() @ R.T
+    f32 = lambda t: t.float().contiguous()
+    col = lambda v: torch.full((n, 1), float(v), device=dev)
+    d32 = f32(d)
+    return dict(origins=f32(o), directions=d32, viewdirs=f32(d / torch.linalg.norm(d)),  # Frobenius norm of the whole array (sic)
+                radii=col(0.0005), imageplane=torch.zeros(n, 2, device=dev), lossmult=col(1.0), near=col(2.0 * scale_factor),
+                far=col(500.0 * scale_factor), cam_idx=col(-1.0), base_x=d32, base_y=d32, rgb=torch.zeros(n, 3, device=dev),
+                semantic=torch.full((n,), 255.0, device=dev), mask=torch.ones(n, device=dev))
 
 
 def supervise(batch: Dict[str, torch.Tensor], rot_seed: int = 0, scale_factor: float = 1.0 / 250.0) -> Dict[str, torch.Tensor]:

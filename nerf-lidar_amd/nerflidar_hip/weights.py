@@ -143,3 +143,48 @@ def synth_object_state_dict(obj_cfgs: Dict[int, MLPConfig], n_tracks: int, seed:
             u = synth.uniform(seed, 7000 + t, (2, lat), 1e-7, 1.0).astype(np.float64)
             sd[f"latent_vector_dict.obj_latent_{t}"] = (np.sqrt(-2 * np.log(u[0])) * np.cos(2 * np.pi * u[1])).astype(np.float32)
     return sd
+
+
+_PRIMES = (1, 2654435761, 805459861)  # gridencoder.cu:54
+
+
+def inflate_hashmaps(sd: Dict[str, np.ndarray], mc: ModelConfig, log2_hashmap: int):
+    """The SAME field on larger hash maps: (state_dict, ModelConfig) whose grids have 2^log2_hashmap rows per hashed level and evaluate,
+    bit for bit, the function the given (smaller-map) parameters evaluate.
+
+    A level that is hashed in both layouts reads row `hash(p) mod T` (gridencoder.cu:66-84); with T_small | T_big,
+    (h mod T_big) mod T_small = h mod T_small, so tiling the small level T_big / T_small times reproduces every look-up.  A level that
+    is hashed in the small layout but fits the big one densely gets row `x + G y + G^2 z` filled with the small level's row
+    `hash(x, y, z) mod T_small`.  Dense-in-both levels are copied.  Purpose: a checkpoint trained with small maps (a few MB, committable)
+    becomes a model with the memory footprint and the access pattern of the full-size configuration (229 MiB NerfMLP table) without
+    changing one rendered value - the benchmark's trained-scene workload."""
+    import dataclasses
+    big = dataclasses.replace(mc, nerf_mlp=dataclasses.replace(mc.nerf_mlp, grid_log2_hashmap_size=log2_hashmap),
+                              prop_mlp=dataclasses.replace(mc.prop_mlp, grid_log2_hashmap_size=log2_hashmap), config=dataclasses.replace(mc.config))
+    out = {k: v for k, v in sd.items() if ".encoder." not in k}
+    for (prefix, cs), (_, cb) in zip(mlp_names(mc), mlp_names(big)):
+        if cb.grid_log2_hashmap_size < cs.grid_log2_hashmap_size:
+            raise ValueError("inflate_hashmaps only grows the maps")
+        off_s, sizes, _ = grid_layout(cs)
+        off_b, sizes_b, _ = grid_layout(cb)
+        small = np.asarray(sd[f"{prefix}.encoder.embeddings"])
+        table = np.zeros((int(off_b[-1]), small.shape[1]), small.dtype)
+        for l, G in enumerate(int(g) for g in sizes):
+            ts, tb = int(off_s[l + 1] - off_s[l]), int(off_b[l + 1] - off_b[l])
+            src, dst = small[off_s[l]:off_s[l + 1]], table[off_b[l]:off_b[l + 1]]
+            dense_s, dense_b = G ** 3 <= ts, G ** 3 <= tb
+            if dense_s:                      # dense in both (the big map is at least as large)
+                dst[:ts] = src
+            elif not dense_b:                # hashed in both
+                if tb % ts:
+                    raise ValueError(f"{prefix} level {l}: {tb} rows are not a multiple of {ts}")
+                dst[:] = np.tile(src, (tb // ts, 1))
+            else:                            # hashed -> dense
+                ax = np.arange(G, dtype=np.uint64)
+                h = ((ax * np.uint64(_PRIMES[0]))[None, None, :] & np.uint64(0xFFFFFFFF)) ^ \
+                    ((ax * np.uint64(_PRIMES[1]))[None, :, None] & np.uint64(0xFFFFFFFF)) ^ \
+                    ((ax * np.uint64(_PRIMES[2]))[:, None, None] & np.uint64(0xFFFFFFFF))        # [z, y, x], x fastest = dense row order
+                dst[:G ** 3] = src[(h % np.uint64(ts)).reshape(-1).astype(np.int64)]
+        out[f"{prefix}.encoder.embeddings"] = table
+        out[f"{prefix}.encoder.offsets"], out[f"{prefix}.encoder.grid_sizes"] = off_b, sizes_b
+    return out, big

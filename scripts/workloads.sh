@@ -3,11 +3,12 @@
 # C2 (the benchmark), C2 with fp16 tables, the reference's 32 x 1100 sweep, the shipped architecture (REF), C1, C2 as one uniform level (C2S),
 # the exact-f32 modes, and config C3 (4 cameras 1024 x 768) through render_image.
 run() {
-  timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | \
-    ARGS="$*" python -c "import sys,json,os; d=json.loads(sys.stdin.read()); print(os.environ['ARGS'] or 'C2', '|', int(d['value']), 'rays/s', round(d['ms_per_step'],3), 'ms', d['kernel_ms'], 'mlp', round(d['roofline']['achieved'],1), 'TFLOP/s', 'encode', round(d['roofline_gather']['achieved']/1e3,2), 'TB/s algorithmic')"
+  timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" 2>>gpurun_out/workloads.err | tail -1 | \
+    ARGS="$*" python -c "import sys,json,os; d=json.loads(sys.stdin.read()); print(os.environ['ARGS'] or 'C2', '|', int(d['value']), 'rays/s', round(d['ms_per_step'],3), 'ms', d['kernel_ms'], 'mlp', round(d['roofline']['achieved'],1), 'TFLOP/s', 'encode', round(d['roofline_gather']['algorithmic_gather_GBps']/1e3,2), 'TB/s algorithmic')"
 }
 python -c "import sys; sys.path.insert(0,'nerf-lidar_amd'); from nerflidar_hip import buildinfo; print('# binary', buildinfo.binary_sha()[:16], 'stale:', buildinfo.stale())"
 run
+run --static-origin
 run --table-dtype f16
 run --width 1100
 run --workload REF

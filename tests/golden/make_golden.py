@@ -674,9 +674,13 @@ def gen_trained():
     (render_lidar.py:74) - and renders rays of a held-out sweep (a sensor position no training ray started from) with
     `Model.forward`; stored: inputs, the reference's outputs for every ray, per-sample history of the first rays."""
     print("trained-scene fixture (reference restore_checkpoint + Model.forward)")
-    import glob
     import json
-    ck_dir = os.path.join(HERE, "ckpt_trained")
+    for sub in ("ckpt_trained", "ckpt_trained_c2"):   # the shipped architecture + intensity head; the benchmark architecture (C2)
+        _gen_trained_one(os.path.join(HERE, sub))
+
+
+def _gen_trained_one(ck_dir):
+    import json
     summ = json.load(open(os.path.join(ck_dir, "train_summary.json")))["summary"]
     wl, lg = summ["workload"], summ["log2_hashmap"]
     mc = nconfig.workload(wl, lg)

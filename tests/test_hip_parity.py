@@ -741,6 +741,32 @@ def test_static_sweep_replays_from_a_hip_graph():
         assert float(tile.abs().sum()) > 0
 
 
+def test_captured_sweep_owns_its_workspace():
+    """the graph carries the raw workspace address.  An eager render with MORE rays after the capture used to make the model
+    replace (free) that arena; the capture now owns it, so the replay stays correct and the model's eager arena is a different tensor."""
+    from nerflidar_hip.models import CapturedRender, Model
+    mc = nconfig.workload("REF", 12)
+    sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
+    model = Model(mc, sd, device=DEV)
+    small = {k: cu(v) for k, v in nlidar.synthetic_sweep(width=16, seed=0, beams=nlidar.LIDAR_ANGLES[::4]).items()}
+    big = {k: cu(v) for k, v in nlidar.synthetic_sweep(width=512, seed=1).items()}
+    want, _ = model.render_rays(small, scale_factor=1 / 250)
+    want = {k: v.clone() for k, v in want.items()}
+    cap = CapturedRender(model, small, scale_factor=1 / 250)
+    assert model._ws is None and cap._ws is not None
+    addr = cap._ws.data_ptr()
+    model.render_rays(big, scale_factor=1 / 250)                       # larger n: the model allocates ITS arena
+    junk = [torch.full((cap._ws.numel() // 4,), float("nan"), device=DEV) for _ in range(3)]  # would land in a freed arena
+    assert model._ws is not None and model._ws.data_ptr() != addr and cap._ws.data_ptr() == addr
+    for v in cap.out.values():
+        v.zero_()
+    out = cap.replay()
+    torch.cuda.synchronize()
+    for k in ("depth", "semantic", "labels", "rgb", "acc", "points"):
+        assert torch.equal(out[k], want[k]), k
+    del junk
+
+
 @pytest.mark.parametrize("table_dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("workload,log2", [("C2", 14), ("REF", 21), ("C2", 10)])
 def test_fast_level_body_is_bit_identical_to_the_generic_one(workload, log2, table_dtype):

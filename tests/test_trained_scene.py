@@ -18,13 +18,19 @@ from conftest import GOLDEN, golden
 from nerflidar_hip import checkpoints as nckpt, config as nconfig, scene as nscene, lidar as nlidar
 from oracle import nlr_oracle as orc
 
-CKPT = os.path.join(GOLDEN, "ckpt_trained")
-FIX = "fwd_TRAINED_REFI"
+# two trained checkpoints: the shipped architecture + intensity head (2 x 256 view MLP, 32 final samples) and the benchmark
+# architecture C2 (8 x 256, 128 final samples; also bench.py's `trained_scene` workload)
+CASES = {"REFI": ("ckpt_trained", "fwd_TRAINED_REFI"), "C2": ("ckpt_trained_c2", "fwd_TRAINED_C2")}
 T = torch.from_numpy
 
 
-def _setup():
-    g = golden(FIX)
+def _ckpt(case):
+    return os.path.join(GOLDEN, CASES[case][0])
+
+
+def _setup(case="REFI"):
+    CKPT = _ckpt(case)
+    g = golden(CASES[case][1])
     summ = json.load(open(os.path.join(CKPT, "train_summary.json")))["summary"]
     mc = nconfig.workload(summ["workload"], summ["log2_hashmap"])
     sd, step = nckpt.load_checkpoint(CKPT)
@@ -39,10 +45,11 @@ def _setup():
     return g, mc, keep, batch
 
 
-def test_fixture_rays_are_the_held_out_sweep():
+@pytest.mark.parametrize("case", list(CASES))
+def test_fixture_rays_are_the_held_out_sweep(case):
     """The fixture's rays are rows `ray_index` of `lidar.synthetic_sweep(sweep_idx=100)` (viewdirs with the whole sweep's Frobenius
     norm), a sensor position outside the 64 the training batches draw from."""
-    g, mc, sd, batch = _setup()
+    g, mc, sd, batch = _setup(case)
     full = nlidar.synthetic_sweep(width=int(g["width"]), seed=0, sweep_idx=int(g["sweep_idx"]))
     for k in ("origins", "directions", "viewdirs", "radii", "near", "far"):
         np.testing.assert_array_equal(full[k][g["ray_index"]], batch[k])
@@ -50,17 +57,19 @@ def test_fixture_rays_are_the_held_out_sweep():
     assert np.abs(train_pos - batch["origins"][0]).max(-1).min() > 1e-4
 
 
-def test_checkpoint_infers_the_trained_architecture():
-    g, mc, sd, batch = _setup()
+@pytest.mark.parametrize("case", list(CASES))
+def test_checkpoint_infers_the_trained_architecture(case):
+    g, mc, sd, batch = _setup(case)
     inferred = nckpt.infer_model_config(sd, base=mc)
     assert inferred.nerf_mlp.grid_log2_hashmap_size == int(g["log2_hashmap"]) and inferred.config.use_intensity
     assert inferred.level_samples() == mc.level_samples()
 
 
-def test_oracle_matches_reference_on_the_trained_scene():
+@pytest.mark.parametrize("case", list(CASES))
+def test_oracle_matches_reference_on_the_trained_scene(case):
     """The CPU oracle on the restored weights against the reference's own run: on a smooth field the two fp32 evaluations agree to
     1e-5 - two orders below the white-noise fixtures - which pins the oracle on a realistic scene."""
-    g, mc, sd, batch = _setup()
+    g, mc, sd, batch = _setup(case)
     rend, hist = orc.model_forward(sd, mc, {k: T(np.ascontiguousarray(v)) for k, v in batch.items()})
     r = rend[-1]
     d = np.abs(r["depth"].numpy() - g["out_depth"])
@@ -71,10 +80,27 @@ def test_oracle_matches_reference_on_the_trained_scene():
     assert np.abs(hist[-1]["weights"][:K].numpy() - g["hist2_weights"]).max() <= 2e-4
 
 
-def test_trained_scene_is_a_scene():
+def test_inflated_hash_maps_evaluate_the_same_field():
+    """`weights.inflate_hashmaps` (bench.py's trained-scene workload: the committed small-map checkpoint on full-size maps): the oracle
+    renders the inflated parameters to the SAME numbers - tiling a hashed level and re-indexing a hashed level that becomes dense
+    reproduce every look-up exactly (gridencoder.cu:66-84)."""
+    from nerflidar_hip import weights as nweights
+    g, mc, sd, batch = _setup("REFI")
+    sub = {k: T(np.ascontiguousarray(v[:96])) for k, v in batch.items()}
+    want, _ = orc.model_forward(sd, mc, sub)
+    for lg in (15, 18):    # 15: all hashed levels stay hashed; 18: level 1 and 2 (33^3, 65^3 rows) become dense
+        sdb, mcb = nweights.inflate_hashmaps(sd, mc, lg)
+        assert mcb.nerf_mlp.grid_log2_hashmap_size == lg and sdb["nerf_mlp.encoder.embeddings"].shape[0] > sd["nerf_mlp.encoder.embeddings"].shape[0]
+        got, _ = orc.model_forward(sdb, mcb, sub)
+        for k in ("depth", "intensity", "semantic", "rgb"):
+            np.testing.assert_array_equal(got[-1][k].numpy(), want[-1][k].numpy(), err_msg=f"log2 {lg} {k}")
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_trained_scene_is_a_scene(case):
     """The reference's rendering of the checkpoint against the analytic ground truth: a trained field, not noise (median range error
     below half a metre on rays out to 70 m, > 95 % of the labels right)."""
-    g, mc, sd, batch = _setup()
+    g, mc, sd, batch = _setup(case)
     gt = nscene.cast(T(batch["origins"]), T(batch["directions"]), nlidar.seeded_rotation(0), 1 / 250)
     err_m = np.abs(g["out_depth"] - gt["depth"].numpy()) * 250
     assert np.median(err_m) < 0.5, np.median(err_m)
@@ -86,17 +112,18 @@ def test_trained_scene_is_a_scene():
 @pytest.fixture(scope="module")
 def gpu_models():
     from nerflidar_hip import _lib
-    return {p: nckpt.model_from_checkpoint(CKPT, base=_setup()[1], device="cuda:0", precision=p)[0]
-            for p in (_lib.PREC_F32, _lib.PREC_MIXED, _lib.PREC_FAST)}
+    return {(c, p): nckpt.model_from_checkpoint(_ckpt(c), base=_setup(c)[1], device="cuda:0", precision=p)[0]
+            for c in CASES for p in (_lib.PREC_F32, _lib.PREC_MIXED, _lib.PREC_FAST)}
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", list(CASES))
 @pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("path", ["history", "render"])
-def test_trained_scene_max_gates(gpu_models, precision, path):
+def test_trained_scene_max_gates(gpu_models, case, precision, path):
     """MAXIMUM gates on every ray of the fixture (north_star: depth / intensity within 1e-3, labels bit-exact)."""
-    g, mc, sd, batch = _setup()
-    model = gpu_models[precision]
+    g, mc, sd, batch = _setup(case)
+    model = gpu_models[(case, precision)]
     b = {k: T(np.ascontiguousarray(v)).cuda() for k, v in batch.items()}
     if path == "history":
         rend, hist = model(False, b, train_frac=1.0, compute_extras=True)
@@ -130,15 +157,16 @@ def test_trained_scene_max_gates(gpu_models, precision, path):
 
 
 @pytest.mark.gpu
-def test_trained_full_sweep_against_oracle(gpu_models):
+@pytest.mark.parametrize("case", list(CASES))
+def test_trained_full_sweep_against_oracle(gpu_models, case):
     """The whole held-out 32 x 1024 sweep (32 768 rays) on the GPU against the CPU oracle on 4 096 of its rays, maxima again."""
-    g, mc, sd, _ = _setup()
+    g, mc, sd, _ = _setup(case)
     full = nlidar.synthetic_sweep(width=1024, seed=0, sweep_idx=int(g["sweep_idx"]))
-    idx = np.linspace(0, full["origins"].shape[0] - 1, 4096).astype(np.int64)
+    idx = np.linspace(0, full["origins"].shape[0] - 1, 4096 if case == "REFI" else 1024).astype(np.int64)
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     rend, _ = orc.model_forward(sd, mc, {k: T(np.ascontiguousarray(v[idx])) for k, v in full.items()})
     ref = rend[-1]
-    r, _ = gpu_models[2].render_rays({k: T(v).cuda() for k, v in full.items()}, scale_factor=1 / 250)
+    r, _ = gpu_models[(case, 2)].render_rays({k: T(v).cuda() for k, v in full.items()}, scale_factor=1 / 250)
     d = np.abs(r["depth"].cpu().numpy()[idx] - ref["depth"].numpy())
     i = np.abs(r["intensity"].cpu().numpy()[idx] - ref["intensity"].numpy())
     lab = r["labels"].cpu().numpy()[idx] != ref["semantic"].numpy().argmax(-1)
