@@ -30,6 +30,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 H_BEAMS, W_COLS = 32, 1024
 PMC_PROFILE = "r04_pmc_traffic.json"  # scripts/pmc_traffic.sh on the final binary of the round
+MFMA_BF16_SUSTAINED_TFLOPS = 1776.0  # measured, scripts/micro/mfma_shape4 sustained 10 s (profiles/r04_power_trace.txt)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 KNAMES = ["resample", "prop", "encode", "direnc", "mlp", "composite"]
 
@@ -61,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--ckpt", default=None, help="render a TRAINED checkpoint (reference format, nerflidar_hip.checkpoints) instead of the seeded "
                     "synthetic weights; the architecture comes from the file, sampling counts from --workload (or the train_summary.json "
                     "`python -m nerflidar_hip.train_scene` leaves beside it)")
+    ap.add_argument("--weight-scale", type=float, default=None, help="diagnostic (profiles/r04_power_trace.txt): multiply every synthetic "
+                    "parameter by this factor; 0 renders all-zero weights and tables - the same instruction stream with no operand toggling")
     ap.add_argument("--inflate-log2", type=int, default=None, help="with --ckpt: re-lay the checkpoint's hash maps out at 2^N rows per hashed "
                     "level (nerflidar_hip.weights.inflate_hashmaps: the same field bit for bit, with the footprint and the access pattern "
                     "of the larger maps; 21 = the full-size configuration)")
@@ -346,6 +349,8 @@ def main():
     else:
         mc = nconfig.workload(args.workload, args.log2_hashmap)
         sd = nweights.synth_state_dict(mc, seed=0, trained_like=True)
+        if args.weight_scale is not None:
+            sd = {k: (v * np.float32(args.weight_scale) if v.dtype == np.float32 else v) for k, v in sd.items()}
     model = Model(mc, sd, device=dev, precision=args.precision, table_dtype=tdt)
     width = args.width * (world if args.scaling == "weak" else 1)
     emul = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
@@ -466,7 +471,7 @@ def main():
         bsha, ssha = buildinfo.binary_sha(), buildinfo.kernel_source_sha()
         prof = os.path.join(ROOT, "profiles", PMC_PROFILE)
         plain = (world == 1 and args.workload == "C2" and not args.chunk and not emul and args.width == W_COLS and args.table_dtype == "f32"
-                 and args.precision == 2 and args.log2_hashmap is None and not args.ckpt and not args.static_origin)
+                 and args.precision == 2 and args.log2_hashmap is None and not args.ckpt and not args.static_origin and args.weight_scale is None)
         traffic, tnote = pmc_traffic(prof, bsha, ssha, "nlr_mlp_kernel", plain)
         # second ceiling: the gather side, priced in bytes that really cross the L2's memory-side port.  achieved = PMC counter
         # bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section; the committed profile of THIS binary) / the
@@ -530,7 +535,10 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "roofline": {"kernel": "nlr_mlp_kernel", "bound": "mfma", "achieved": achieved,
                          "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote},
+                         "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote,
+                         "sustained_peak": MFMA_BF16_SUSTAINED_TFLOPS, "frac_of_sustained": achieved / MFMA_BF16_SUSTAINED_TFLOPS,
+                         "sustained_note": "what this chip holds on LDS-fed bf16 MFMAs with random operands at its power limit (1 332 W, 2.12 GHz; "
+                                           "2 056 TFLOP/s at 2.39 GHz on all-zero operands): profiles/r04_power_trace.txt"},
             "roofline_gather": rg,
             "roofline_prop": rp,
             "kernel_source_sha": bsha[:16],

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -65,16 +66,39 @@ __global__ void __launch_bounds__(256, 1) k(const uint4 *__restrict__ w, const u
     if (threadIdx.x == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
 }
 #define NV 5
-int main() {
+int main(int argc, char **argv) {
+    // sustain mode (round 4, profiles/r04_power_trace.txt): `mfma_shape4 <seconds> [zero]` keeps variant 0 (fragments from LDS into VGPRs, 4 MFMAs
+    // each: the structure of nlr_mlp_kernel's hidden layers) running for that long and prints its rate once a second; `zero` feeds all-zero
+    // operands (same instruction stream, no operand toggling) to show how much of the sustained clock is the DATA's power.
+    const double sustain = argc > 1 ? atof(argv[1]) : 0.0;
+    const bool zero = argc > 2 && !strcmp(argv[2], "zero");
     const int blocks = 256, steps = 1 << 18;
     std::vector<uint16_t> h((size_t)FRAGS * 64 * 8), hx((size_t)blocks * 256 * 16 * 8);
     uint32_t s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; float f = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; uint32_t u; memcpy(&u, &f, 4); return (uint16_t)(u >> 16); };
-    for (auto &v : h) v = rnd();
-    for (auto &v : hx) v = rnd();
+    for (auto &v : h) v = zero ? 0 : rnd();
+    for (auto &v : hx) v = zero ? 0 : rnd();
     uint4 *w, *x; float *out; unsigned long long *clk;
     hipMalloc(&w, h.size() * 2); hipMalloc(&x, hx.size() * 2); hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, blocks * 16);
     hipMemcpy(w, h.data(), h.size() * 2, hipMemcpyHostToDevice); hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+    if (sustain > 0) {
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        double total = 0;
+        while (total < sustain * 1e3) {
+            hipEventRecord(a);
+            int n = 0;
+            for (; n < 100; ++n) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, w, x, out, steps, clk);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            total += ms;
+            unsigned long long hc[512]; hipMemcpy(hc, clk, sizeof(hc), hipMemcpyDeviceToHost);
+            double mhz = 0; for (int i = 0; i < blocks; ++i) mhz += (double)hc[2 * i] / (double)hc[2 * i + 1] * 100.0; mhz /= blocks;
+            printf("sustain %s t=%.1f s: %.0f TFLOP/s, in-kernel clock %.0f MHz\n", zero ? "zero-operands" : "random-operands", total / 1e3,
+                   (double)blocks * 4 * steps * 32768.0 * 2.0 * n / ms / 1e9, mhz);
+            fflush(stdout);
+        }
+        return 0;
+    }
     const char *names[NV] = {"0: frag VGPR, acc VGPR", "1: frag AGPR, acc VGPR", "2: frag VGPR, acc AGPR", "3: frag AGPR, acc AGPR", "4: no LDS reads (floor)"};
     for (int rep = 0; rep < 2; ++rep)
         for (int v = 0; v < NV; ++v) {
