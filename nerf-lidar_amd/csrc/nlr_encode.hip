@@ -312,6 +312,34 @@ __global__ void __launch_bounds__(256) nlr_prop8g_kernel(CastParams cp, GridPara
 // instruction stream (see nlr_level_fast.h) and that a lane's validity (active multisample, point inside the unit cube) is decided
 // once instead of once per level.
 // =============================================================================================================
+// Workgroup order.  The hardware deals the workgroups of a launch to the 8 XCDs round-robin (workgroup b runs on XCD b mod 8) and every
+// XCD has its own 4 MiB L2.  Consecutive workgroups here are consecutive 32-sample pieces of one ray and then of its neighbour in the batch
+// (for a LiDAR sweep or an image: the next azimuth column / pixel), whose fine-level cells overlap; dealt round-robin, the lines they share
+// are fetched into up to 8 L2s.  nlr_xcd_block hands every XCD CHUNKS of `chunk` consecutive logical workgroups instead: the b-th
+// dispatched workgroup (the q-th of its XCD, q = b / 8) works on logical workgroup ((q / chunk) * 8 + xcd) * chunk + q mod chunk.  Chunks
+// (not one eighth of the launch per XCD) keep the XCDs balanced when rays differ in cost.  The tail that does not fill 8 chunks keeps
+// the identity order.
+__device__ __forceinline__ uint32_t nlr_xcd_block(uint32_t b, uint32_t nblocks, uint32_t chunk) {
+    const uint32_t per = 8u * chunk, full = (nblocks / per) * per;
+    if (b >= full) return b;
+    const uint32_t x = b & 7u, q = b >> 3;
+    return ((q / chunk) * 8u + x) * chunk + (q % chunk);
+}
+
+#define NLR_XCD_CHUNK 32u  // workgroups (of 32 samples) per chunk: 8 rays of a 128-sample level (profiles/r04_encode_experiments.txt)
+
+#ifdef NLR_DBG_ENV
+// Diagnostic builds only (scripts/diag_encode.sh; never in libnerflidar_hip.so): experiment switches of the gather kernels, set from the
+// environment at launch (NLR_ENC_LO / _HI / _NOSCALAR / _NT; NLR_ENC_CHUNK and NLR_ENC_PERSIST are read by the launchers).
+// [0] first level, [1] one past the last level, [3] scalar path off, [4] bit mask of levels gathered non-temporally
+// (the array itself is defined in nlr_level_fast.h, which reads [3])
+#define NLR_DBG_LO nlr_dbg[0]
+#define NLR_DBG_HI nlr_dbg[1]
+#else
+#define NLR_DBG_LO 0
+#define NLR_DBG_HI 99
+#endif
+
 struct RayRegs {
     float o[3], d[3], bx[3], by[3], radius, t0, t1;
 };
@@ -331,9 +359,9 @@ __device__ __forceinline__ RayRegs nlr_load_ray(const CastParams &cp, uint32_t r
 }
 
 template <typename T, int C>
-__global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat,
-                                                          int piece_major) {
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void nlr_encode8_block(const CastParams &cp, const GridParams &gp, int re_weights, float *__restrict__ feat,
+                                                  int piece_major, uint32_t block) {
+    const uint32_t gt = block * 256u + threadIdx.x;
     const uint32_t M = cp.N * cp.S;
     uint32_t m = gt >> 3;
     const uint32_t j = gt & 7;
@@ -350,7 +378,7 @@ __global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridPar
     float r[C];  // this lane's contribution to the level; stays 0 in lanes without a point
 #pragma unroll
     for (int c = 0; c < C; ++c) r[c] = 0.0f;
-    for (uint32_t l = 0; l < gp.L; ++l) {
+    for (uint32_t l = NLR_DBG_LO; l < gp.L && l < (uint32_t)NLR_DBG_HI; ++l) {
         if (valid) {
             const float werf = re_weights ? nlr_erf_weight_fast(inv_s8, gp.inv_gsize[l]) : 1.0f;
             if (gp.mode[l] == 0) nlr_level_fast<T, C, 0>(gp, l, g.x0, g.x1, g.x2, werf, r);
@@ -360,15 +388,31 @@ __global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridPar
         nlr_group8_sum_to(r, a);
         if (in && j == (l & 7)) {  // spread the row stores over the lanes of the group (layouts: see nlr_encode8g_kernel)
             float *f = (piece_major && C == 4) ? feat + ((size_t)l * M + m) * 4 : feat + (size_t)m * gp.L * C + l * C;
+            if constexpr (C == 4) {
+                // one 16-byte non-temporal store: the features are a 0.67 GB stream per sweep that the MLP kernel reads once; kept out of
+                // the L2's recently-used set they do not evict table lines the next samples will gather again
+                const nlr_f4 q = {a[0] * inv_n, a[1] * inv_n, a[2] * inv_n, a[3] * inv_n};
+                __builtin_nontemporal_store(q, (nlr_f4 *)f);
+            } else {
 #pragma unroll
-            for (int c = 0; c < C; ++c) f[c] = a[c] * inv_n;
+                for (int c = 0; c < C; ++c) f[c] = a[c] * inv_n;
+            }
         }
     }
 }
 
+// One workgroup per 32 samples, or (nblocks > gridDim.x) a persistent grid that walks the logical workgroups with the grid's stride; the
+// dispatch slot decides the XCD, nlr_xcd_block the samples (see there).
+template <typename T, int C>
+__global__ void __launch_bounds__(256) nlr_encode8_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat,
+                                                          int piece_major, uint32_t nblocks, uint32_t chunk) {
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
+        nlr_encode8_block<T, C>(cp, gp, re_weights, feat, piece_major, chunk ? nlr_xcd_block(b, nblocks, chunk) : b);
+}
+
 template <typename T, int C, int LMAX>
 __global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParams gp, PropMlpParams mp, int re_weights,
-                                                        float *__restrict__ density, float *__restrict__ feat_out) {
+                                                        float *__restrict__ density, float *__restrict__ feat_out, uint32_t nblocks, uint32_t chunk) {
     __shared__ float sw[64 * 16 + 128];  // w1 [64, F] | b1 [64] | w2 [64]
     for (uint32_t i = threadIdx.x; i < 64 * mp.F; i += 256) sw[i] = mp.w1[i];
     if (threadIdx.x < 64) {
@@ -376,7 +420,8 @@ __global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParam
         sw[64 * mp.F + 64 + threadIdx.x] = mp.w2[threadIdx.x];
     }
     __syncthreads();
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t lb = blockIdx.x; lb < nblocks; lb += gridDim.x) {  // (one workgroup per 32 samples, or a persistent grid: see nlr_encode8_kernel)
+    const uint32_t gt = (chunk ? nlr_xcd_block(lb, nblocks, chunk) : lb) * 256u + threadIdx.x;
     const uint32_t M = cp.N * cp.S;
     uint32_t m = gt >> 3;
     const uint32_t j = gt & 7;
@@ -433,6 +478,7 @@ __global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParam
         const float x = (praw[0] + mp.b2) + mp.density_bias;
         density[m] = x > 20.0f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20), models.py:1116
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -598,7 +644,21 @@ static bool nlr_force_generic() {
     return e && e[0] == '1';
 }
 
+#ifdef NLR_DBG_ENV
+static void nlr_dbg_upload(hipStream_t st) {
+    int v[8] = {0, 99, 0, 0, 0, 0, 0, 0};
+    if (const char *e = getenv("NLR_ENC_LO")) v[0] = atoi(e);
+    if (const char *e = getenv("NLR_ENC_HI")) v[1] = atoi(e);
+    if (const char *e = getenv("NLR_ENC_NOSCALAR")) v[3] = atoi(e);
+    if (const char *e = getenv("NLR_ENC_NT")) v[4] = (int)strtol(e, nullptr, 0);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(nlr_dbg), v, sizeof(v), 0, hipMemcpyHostToDevice, st);
+}
+#endif
+
 int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, int piece_major, hipStream_t st) {
+#ifdef NLR_DBG_ENV
+    nlr_dbg_upload(st);
+#endif
     // 8 lanes per sample with a 32-bit lane index (the kernels compute N * S in 32 bits)
     NLR_CHECK_ARG((uint64_t)cp.N * cp.S * 8 < (1ull << 32), "encode: N * S = %llu samples do not fit the 32-bit lane index (chunk the rays)",
                   (unsigned long long)cp.N * cp.S);
@@ -606,9 +666,15 @@ int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights
     if (cp.n <= 8) {  // multisample-parallel mapping
         dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
         const bool fast = nlr_level_fast_ok(gp) && !nlr_force_generic();
+        uint32_t chunk = NLR_XCD_CHUNK;
+        dim3 gridp = grid8;
+#ifdef NLR_DBG_ENV
+        if (const char *e = getenv("NLR_ENC_CHUNK")) chunk = (uint32_t)atoi(e);
+        if (const char *e = getenv("NLR_ENC_PERSIST")) gridp.x = (uint32_t)atoi(e) * 256u < grid8.x ? (uint32_t)atoi(e) * 256u : grid8.x;
+#endif
 #define NLR_ENC8(T, C)                                                                                                               \
     do {                                                                                                                             \
-        if (fast) hipLaunchKernelGGL((nlr_encode8_kernel<T, C>), grid8, block8, 0, st, cp, gp, re_weights, feat, piece_major);       \
+        if (fast) hipLaunchKernelGGL((nlr_encode8_kernel<T, C>), gridp, block8, 0, st, cp, gp, re_weights, feat, piece_major, grid8.x, chunk); \
         else hipLaunchKernelGGL((nlr_encode8g_kernel<T, C>), grid8, block8, 0, st, cp, gp, re_weights, feat, piece_major);           \
     } while (0)
         if (gp.table_dtype == 0) {
@@ -657,6 +723,9 @@ int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1,
     NLR_CHECK_ARG((uint64_t)cp.N * cp.S * 8 < (1ull << 32), "proposal level: N * S = %llu samples do not fit the 32-bit lane index (chunk the rays)",
                   (unsigned long long)cp.N * cp.S);
     const uint32_t M = cp.N * cp.S;
+#ifdef NLR_DBG_ENV
+    nlr_dbg_upload(st);
+#endif
     PropMlpParams mp;
     mp.w1 = w1;
     mp.b1 = b1;
@@ -668,9 +737,15 @@ int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1,
     if (cp.n <= 8) {
         dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
         const bool fast = nlr_level_fast_ok(gp) && !nlr_force_generic();
+        uint32_t chunk = NLR_XCD_CHUNK;
+        dim3 gridp = grid8;
+#ifdef NLR_DBG_ENV
+        if (const char *e = getenv("NLR_ENC_CHUNK")) chunk = (uint32_t)atoi(e);
+        if (const char *e = getenv("NLR_ENC_PERSIST")) gridp.x = (uint32_t)atoi(e) * 256u < grid8.x ? (uint32_t)atoi(e) * 256u : grid8.x;
+#endif
 #define NLR_PROP8(T, C, LM)                                                                                                                    \
     do {                                                                                                                                       \
-        if (fast) hipLaunchKernelGGL((nlr_prop8_kernel<T, C, LM>), grid8, block8, 0, st, cp, gp, mp, re_weights, density, feat_out);           \
+        if (fast) hipLaunchKernelGGL((nlr_prop8_kernel<T, C, LM>), gridp, block8, 0, st, cp, gp, mp, re_weights, density, feat_out, grid8.x, chunk); \
         else hipLaunchKernelGGL((nlr_prop8g_kernel<T, C, LM>), grid8, block8, 0, st, cp, gp, mp, re_weights, density, feat_out);               \
     } while (0)
         const bool f32t = gp.table_dtype == 0;

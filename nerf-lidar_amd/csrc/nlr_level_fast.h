@@ -23,6 +23,9 @@
 #include "nlr_grid_level.h"
 
 typedef float nlr_f2 __attribute__((ext_vector_type(2)));
+#ifdef NLR_DBG_ENV
+__device__ int nlr_dbg[8] = {0, 99, 0, 0, 0, 0, 0, 0};  // diagnostic builds only, see nlr_encode.hip
+#endif
 
 template <typename T, int C>
 struct NlrEntry;  // bytes per table entry as a shift, and the gather of one entry from a 32-bit byte offset
@@ -39,11 +42,17 @@ struct NlrEntry<float, 2> {
         v[0] = t.x, v[1] = t.y;
     }
 };
+typedef float nlr_f4 __attribute__((ext_vector_type(4)));
 template <>
 struct NlrEntry<float, 4> {
     static constexpr int E = 4;
     static __device__ __forceinline__ void ld(const char *base, uint32_t off, float (&v)[4]) {
         const float4 t = *(const float4 *)(base + off);
+        v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+    }
+    // non-temporal form (global_load_dwordx4 ... nt): the line is not kept in L2 at the expense of lines that will be used again
+    static __device__ __forceinline__ void ld_nt(const char *base, uint32_t off, float (&v)[4]) {
+        const nlr_f4 t = __builtin_nontemporal_load((const nlr_f4 *)(base + off));
         v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
     }
 };
@@ -244,6 +253,9 @@ __device__ __forceinline__ void nlr_level_fast(const GridParams &gp, uint32_t le
     if constexpr (DW >= 1) {
         u0 = __builtin_amdgcn_readfirstlane(g0), u1 = __builtin_amdgcn_readfirstlane(g1), u2 = __builtin_amdgcn_readfirstlane(g2);
         uniform = __builtin_amdgcn_ballot_w64((g0 != u0) | (g1 != u1) | (g2 != u2)) == 0ull;
+#ifdef NLR_DBG_ENV
+        if (nlr_dbg[3]) uniform = false;
+#endif
     }
     if (uniform) {
         if constexpr (DW >= 1) {
@@ -288,8 +300,21 @@ __device__ __forceinline__ void nlr_level_fast(const GridParams &gp, uint32_t le
 #pragma unroll
             for (int c8 = 0; c8 < 8; c8 += 2) NlrPair<T, C>::ld(base, off[c8], v[c8], v[c8 + 1]);  // off[c8 + 1] = off[c8] + one entry
         } else {
+#ifdef NLR_DBG_ENV
+            if constexpr (sizeof(T) == 4 && C == 4) {
+                if ((nlr_dbg[4] >> level) & 1) {
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) NlrEntry<T, C>::ld(base, off[c8], v[c8]);
+                    for (int c8 = 0; c8 < 8; ++c8) NlrEntry<T, C>::ld_nt(base, off[c8], v[c8]);
+                } else {
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; ++c8) NlrEntry<T, C>::ld(base, off[c8], v[c8]);
+                }
+            } else
+#endif
+            {
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) NlrEntry<T, C>::ld(base, off[c8], v[c8]);
+            }
         }
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {

@@ -19,11 +19,16 @@ def kernel_source_files():
     return [f for f in files if os.path.isfile(f)]
 
 
-def kernel_source_sha() -> str:
+def kernel_source_sha(flags_file=None) -> str:
+    """Hash of the sources AND of the build's flag stamp (build/flags.txt: compiler, version, architecture, flags, EXTRA - written by the
+    Makefile), so that a library built with other flags (e.g. EXTRA=-DNLR_STAMPS) does not carry the benchmark binary's identity."""
     h = hashlib.sha256()
     for f in kernel_source_files():
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
+    flags_file = flags_file or os.path.join(_PKG, "build", "flags.txt")
+    if os.path.isfile(flags_file):
+        h.update(b"flags\0" + open(flags_file, "rb").read())
     return h.hexdigest()
 
 
@@ -42,4 +47,5 @@ def stale():
 
 
 if __name__ == "__main__":
-    print(kernel_source_sha())
+    import sys
+    print(kernel_source_sha(sys.argv[1] if len(sys.argv) > 1 else None))

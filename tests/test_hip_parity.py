@@ -20,7 +20,8 @@ DEV = "cuda:0"
 
 
 def _names(prefix):
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+    # (fwd_TRAINED_* belong to tests/test_trained_scene.py: their weights come from a checkpoint, not from a seed)
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")) if "TRAINED" not in p)
 
 
 def cu(a):
