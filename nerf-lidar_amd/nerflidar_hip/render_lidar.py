@@ -69,6 +69,60 @@ def drop_rays(res: Dict[str, torch.Tensor], points_lidar: torch.Tensor, unet, ma
     return raydrop.apply_ray_drop(proj, logits[0], mask_thre=mask_thre, place_car=place_car), proj
 
 
+def render_sweep_device(model: Model, batch: Dict[str, torch.Tensor], scale_factor: float) -> Dict[str, torch.Tensor]:
+    """One sweep through ONE `nlr_render_rays` call (no chunk loop, nothing leaves the device): the LiDAR post-step outputs `points`
+    (metres), `labels`, `rgb`, `depth`, `intensity` of render_lidar.py:142-161, written by the compositing kernel itself."""
+    r, _ = model.render_rays(batch, compute_extras=False, scale_factor=scale_factor)
+    return r
+
+
+def sweep_unet_input(res: Dict[str, torch.Tensor], origin_m: torch.Tensor, lidar2world: torch.Tensor, var: bool = True, width: int = 1024):
+    """Rendered sweep -> the UNet's input image (Generate_feature.py:144-167 without the .npy round trip): sensor frame, spherical range
+    projection (RD/lidar_utils.py:215-282 on the GPU), feature stack.  Returns ([1, F, 32, width], the projection dict)."""
+    from . import raydrop
+    pts = to_lidar_frame(res["points"], origin_m, lidar2world)
+    proj = raydrop.range_projection(pts.double(), semantic=res["labels"].float(), rgb=res["rgb"], H=32, W=width)
+    return raydrop.unet_features(proj, var=var), proj
+
+
+def analytic_drop_truth(batch: Dict[str, torch.Tensor], origin_m: torch.Tensor, lidar2world, scale_factor: float, seed: int, sweep_idx: int,
+                        width: int = 1024):
+    """What stands in for the REAL sweep the reference trains the ray-drop UNet against (ray_drop_train.py:80-90: `mask` and `range` of a
+    recorded LiDAR frame): the analytic scene's first hits, with a return kept when its received power - reflectivity x incidence shading
+    x (30 m / range)^2, the `intensity` of nerflidar_hip.scene over range squared - exceeds a per-ray noisy threshold.  Projected with the
+    same range projection as the rendered sweep (the keep flag travels in the semantic channel).  -> gt_mask [32, width] int64,
+    gt_range [32, width] (normalised log range where kept, 0 elsewhere)."""
+    from . import raydrop, scene as nscene
+    rot = nlidar.seeded_rotation(seed)
+    gt = nscene.cast(batch["origins"], batch["directions"], rot, scale_factor)
+    rng_m = gt["depth"] / scale_factor
+    power = gt["intensity"] * (30.0 / rng_m.clamp_min(1.0)) ** 2
+    g = torch.Generator(device=power.device).manual_seed(seed * 7919 + sweep_idx)
+    keep = power > 0.08 * (0.5 + torch.rand(power.shape, device=power.device, generator=g))
+    pts = (batch["origins"] + gt["depth"][:, None] * batch["directions"]) / scale_factor
+    proj = raydrop.range_projection(to_lidar_frame(pts, origin_m, lidar2world).double(), semantic=keep.float(), H=32, W=width)
+    mask = ((proj["proj_semantic"] == 1) & (proj["proj_mask"] == 1)).long()
+    real = proj["proj_range"]
+    lr = torch.clamp(torch.log2(torch.where(real < 0, torch.zeros_like(real), real) + 0.0001 + 1) / 6.5, 0, 1)
+    return mask, lr * mask
+
+
+def raydrop_batch(model: Model, sweep_ids, scale_factor: float = 1.0 / 250.0, seed: int = 0, width: int = 1024, var: bool = True):
+    """BASELINE config 5's input, end to end on the device: render the sweeps, project, stack -> img [B, F, 32, width], gt_mask [B, 32, width],
+    gt_range [B, 32, width] for `raydrop.train_step` (B = len(sweep_ids)), plus the per-sweep projections for `raydrop.apply_ray_drop`."""
+    dev = model.device
+    rot = torch.from_numpy(nlidar.seeded_rotation(seed)).float().to(dev)
+    imgs, masks, ranges, projs = [], [], [], []
+    for idx in sweep_ids:
+        b = {k: torch.from_numpy(v).to(dev) for k, v in nlidar.synthetic_sweep(width=width, seed=seed, scale_factor=scale_factor, sweep_idx=idx).items()}
+        origin_m = b["origins"][0] / scale_factor
+        res = render_sweep_device(model, b, scale_factor)
+        img, proj = sweep_unet_input(res, origin_m, rot, var=var, width=width)
+        m, r = analytic_drop_truth(b, origin_m, rot, scale_factor, seed, idx, width)
+        imgs.append(img[0]); masks.append(m); ranges.append(r); projs.append(proj)
+    return torch.stack(imgs), torch.stack(masks), torch.stack(ranges), projs
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     src = ap.add_mutually_exclusive_group()

@@ -27,3 +27,45 @@ with torch.no_grad():
     for _ in range(n): m(img)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"C5 inference (UNet forward, batch {B}): {dt*1e3:.2f} ms -> {B/dt:.0f} sweeps/s")
+
+# ---- the whole chain from rendered sweeps: render -> project -> stack -> UNet, nothing leaves the device ------------
+from nerflidar_hip import checkpoints as nckpt, config as nconfig, render_lidar as nrl, weights as nweights
+ck = os.path.join(ROOT, "tests", "golden", "ckpt_trained_c2")
+import json
+summ = json.load(open(os.path.join(ck, "train_summary.json")))["summary"]
+sd, _ = nckpt.load_checkpoint(ck); sd, _ = nckpt.split_state_dict(sd)
+mc = nckpt.infer_model_config(sd, nconfig.workload(summ["workload"], summ["log2_hashmap"]))
+sd, mc = nweights.inflate_hashmaps(sd, mc, 21)
+from nerflidar_hip.models import Model
+model = Model(mc, sd, device=dev)
+ids = list(range(100, 108))
+batch = nrl.raydrop_batch(model, ids)            # warm-up
+m.train()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n = 5
+for _ in range(n):
+    img8, gm, gr, projs = nrl.raydrop_batch(model, ids)
+    l, v = raydrop.train_step(m, opt, vl, img8, gm, gr)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print(f"C5 whole chain, training: 8 sweeps rendered (C2 trained checkpoint, full-size maps) + projected + stacked + truth + UNet step: {dt*1e3:.1f} ms -> {8/dt:.0f} sweeps/s")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(n):
+    img8, gm, gr, projs = nrl.raydrop_batch(model, ids)
+torch.cuda.synchronize(); dt_in = (time.perf_counter() - t0) / n
+print(f"   of which input (render + project + stack + analytic truth, 8 sweeps): {dt_in*1e3:.1f} ms")
+m.eval()
+rot = torch.from_numpy(nrl.nlidar.seeded_rotation(0)).float().to(dev)
+sweeps = [{k: torch.from_numpy(v).to(dev) for k, v in nrl.nlidar.synthetic_sweep(width=1024, seed=0, sweep_idx=i).items()} for i in ids]
+def apply_one(b):
+    res = nrl.render_sweep_device(model, b, 1 / 250)
+    img1, proj = nrl.sweep_unet_input(res, b["origins"][0] * 250, rot)
+    with torch.no_grad():
+        logits = m(img1)
+    return raydrop.apply_ray_drop(proj, logits[0])
+apply_one(sweeps[0])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3):
+    for b in sweeps:
+        pts, lab = apply_one(b)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (3 * len(sweeps))
+print(f"C5 whole chain, simulation: render -> project -> stack -> UNet forward -> drop mask -> kept points, per sweep: {dt*1e3:.2f} ms -> {1/dt:.0f} sweeps/s ({pts.shape[0]} of 32768 points kept in the last one)")

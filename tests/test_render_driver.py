@@ -83,8 +83,10 @@ def _worker(rank, world, port, tmp):
 
     class Acc:  # the three members of accelerate.Accelerator that render_image touches
         process_index, num_processes = rank, world
+        calls = 0
 
         def gather(self, t):
+            Acc.calls += 1
             parts = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
             return torch.cat(parts)
@@ -92,11 +94,24 @@ def _worker(rank, world, port, tmp):
     b = _batch(45, seed=3)  # 45 rays, chunks of 16: the last chunk (13 rays) needs one zero ray of padding
     cfg = nconfig.Config(render_chunk_size=16)
     m = FakeModel()
-    out = render_image(m, Acc(), dict(b), False, cfg, image=False, return_weights=True)
     ref = m(False, {k: v for k, v in b.items() if v is not None}, 1, True)
-    for k in ("depth", "rgb", "semantic", "acc"):
-        assert torch.equal(out[k].reshape(ref[0][-1][k].shape), ref[0][-1][k]), k
-    assert torch.equal(out["weights"], ref[1][-1]["weights"])
+    outs = {}
+    for packed in (True, False):
+        Acc.calls = 0
+        torch.manual_seed(5)    # the random subset of the ray bundles (models.py:1495-1503) is drawn after the chunks
+        out = outs[packed] = render_image(m, Acc(), dict(b), False, cfg, image=False, return_weights=True, packed_gather=packed)
+        for k in ("depth", "rgb", "semantic", "acc"):
+            assert torch.equal(out[k].reshape(ref[0][-1][k].shape), ref[0][-1][k]), k
+        assert torch.equal(out["weights"], ref[1][-1]["weights"])
+        chunks = 3                                        # 45 rays in chunks of 16
+        # one collective per chunk, against one per key (4 per-ray keys + 3 bundles x 2 levels + weights = 11) per chunk
+        assert Acc.calls == (chunks if packed else chunks * 11), (packed, Acc.calls)
+    for k in outs[True]:                                   # the two call patterns assemble the same rendering, bit for bit
+        a, c = outs[True][k], outs[False][k]
+        if isinstance(a, list):
+            assert all(torch.equal(x, y) for x, y in zip(a, c)), k
+        else:
+            assert torch.equal(a, c), k
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("1")
