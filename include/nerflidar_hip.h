@@ -78,6 +78,18 @@ int nlr_grid_encode_backward(const float *grad, const float *inputs, const int32
                              uint32_t gridtype, int align_corners, uint32_t interp, int grad_layout,
                              void *stream);
 
+/* The same scatter with a caller-provided workspace (round 4): when `workspace_bytes` >= nlr_grid_backward_workspace_bytes(...) and the batch
+ * is large (B * C >= 2^18), the levels that do not fit an LDS copy are scattered through BINS - corner updates written bucket by bucket
+ * (128 KiB of table per bucket) into the workspace, then accumulated per bucket in LDS and added to the table with coalesced atomics -
+ * instead of one scattered global atomic per merged corner update (csrc/nlr_grid.hip, "Binned scatter").  Same result up to the order
+ * of float additions; workspace NULL or too small = nlr_grid_encode_backward.  C in {1, 2} (proposal / object grids; 0 bytes otherwise). */
+size_t nlr_grid_backward_workspace_bytes(uint32_t B, uint32_t C, uint32_t L, float S, uint32_t H, const int32_t *offsets_host,
+                                         uint32_t gridtype, int align_corners);
+int nlr_grid_encode_backward_ws(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
+                                uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs,
+                                uint32_t gridtype, int align_corners, uint32_t interp, int grad_layout, void *workspace,
+                                size_t workspace_bytes, void *stream);
+
 /* nlr_grad_total_variation <-> grad_total_variation (gridencoder.h:15, cu:506-645; bound by grid.py:176-198).
  *   inputs dev f32 [B, D] already mapped to [0,1] (points outside are skipped); embeddings dev f32 [sO, C];
  *   grad dev f32 [sO, C] is accumulated into (embeddings.grad, between loss.backward() and optimizer.step()):
@@ -422,6 +434,11 @@ int nlr_encode_features_backward(const NlrRays *rays, const float *tdist, uint32
                                  float std_scale, const float *rand_deg, const NlrGridDesc *grid, uint32_t re_weights,
                                  const float *d_features, float *points_tmp /* [N*S*sample_n, 3] scratch */,
                                  float *grad_tmp /* [N*S*sample_n, L*C] scratch */, float *grad_table, void *stream);
+/* ... with the binned scatter's workspace (nlr_grid_backward_workspace_bytes for B = N*S*sample_n points), see nlr_grid_encode_backward_ws */
+int nlr_encode_features_backward_ws(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n, uint32_t sample_m,
+                                    float std_scale, const float *rand_deg, const NlrGridDesc *grid, uint32_t re_weights,
+                                    const float *d_features, float *points_tmp, float *grad_tmp, float *grad_table, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -545,9 +545,22 @@ extern "C" int nlr_encode_features_forward(const NlrRays *rays, const float *tdi
     return nlr_launch_encode(cp, gp, (int)re_weights, features, 0, (hipStream_t)stream);
 }
 
+extern "C" int nlr_encode_features_backward_ws(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n, uint32_t sample_m,
+                                               float std_scale, const float *rand_deg, const NlrGridDesc *grid, uint32_t re_weights,
+                                               const float *d_features, float *points_tmp, float *grad_tmp, float *grad_table, void *workspace,
+                                               size_t workspace_bytes, void *stream);
+
 extern "C" int nlr_encode_features_backward(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n, uint32_t sample_m,
                                             float std_scale, const float *rand_deg, const NlrGridDesc *grid, uint32_t re_weights,
                                             const float *d_features, float *points_tmp, float *grad_tmp, float *grad_table, void *stream) {
+    return nlr_encode_features_backward_ws(rays, tdist, N, S, sample_n, sample_m, std_scale, rand_deg, grid, re_weights, d_features, points_tmp,
+                                           grad_tmp, grad_table, nullptr, 0, stream);
+}
+
+extern "C" int nlr_encode_features_backward_ws(const NlrRays *rays, const float *tdist, uint32_t N, uint32_t S, uint32_t sample_n, uint32_t sample_m,
+                                               float std_scale, const float *rand_deg, const NlrGridDesc *grid, uint32_t re_weights,
+                                               const float *d_features, float *points_tmp, float *grad_tmp, float *grad_table, void *workspace,
+                                               size_t workspace_bytes, void *stream) {
     if (N == 0 || S == 0) return NLR_OK;
     NLR_CHECK_ARG(d_features && grad_table && points_tmp && grad_tmp, "encode_features_backward: NULL tensor");
     CastParams cp;
@@ -560,9 +573,9 @@ extern "C" int nlr_encode_features_backward(const NlrRays *rays, const float *td
     hipLaunchKernelGGL(nlr_encode_expand_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, cp, gp, (int)re_weights, d_features, points_tmp,
                        grad_tmp);
     NLR_LAUNCH_CHECK("nlr_encode_expand_kernel");
-    return nlr_grid_encode_backward(grad_tmp, points_tmp, grid->offsets, grad_table, (uint32_t)B, 3, grid->level_dim, grid->num_levels,
-                                    grid->log2_per_level_scale, grid->base_resolution, nullptr, nullptr, grid->gridtype, (int)grid->align_corners,
-                                    grid->interp, 1, stream);
+    return nlr_grid_encode_backward_ws(grad_tmp, points_tmp, grid->offsets, grad_table, (uint32_t)B, 3, grid->level_dim, grid->num_levels,
+                                       grid->log2_per_level_scale, grid->base_resolution, nullptr, nullptr, grid->gridtype, (int)grid->align_corners,
+                                       grid->interp, 1, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -298,6 +298,46 @@ __global__ void __launch_bounds__(1024) nlr_grid_bwd_lds_kernel(const float *__r
     const float scale = gp.scale[level];
     const float half = gp.align_corners ? 0.0f : 0.5f;
     const uint32_t total = B * C;  // one lane per (point, channel), workgroups stride over the batch
+    if constexpr (C == 1) {
+        // one channel: neighbouring lanes are neighbouring points of a ray and sit in ONE cell of these coarse levels - 64 lanes adding
+        // to one LDS word serialise.  Runs of equal entries inside a 16-lane row are merged first (nlr_run_merge), as the global
+        // scatter does; uniform control flow for the DPP scan, invalid points ride along masked.
+        const int lane = threadIdx.x & 63;
+        for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < total; t0 += gridDim.x * blockDim.x) {
+            const uint32_t t = t0 + threadIdx.x;
+            const bool inb = t < total;
+            const uint32_t b = inb ? t : total - 1;
+            const float x0 = x[(size_t)b * 3 + 0], x1 = x[(size_t)b * 3 + 1], x2 = x[(size_t)b * 3 + 2];
+            const bool valid = inb && !((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
+            const float gc = grad_layout == 0 ? grad[(size_t)level * B + b] : grad[(size_t)b * gp.L + level];
+            float pos[3] = {fmaf(valid ? x0 : 0.5f, scale, half), fmaf(valid ? x1 : 0.5f, scale, half), fmaf(valid ? x2 : 0.5f, scale, half)};
+            uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                pg[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pg[d];
+                if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+            }
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                float ww = 1.0f;
+                uint32_t pl[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    if ((c8 >> d) & 1) {
+                        ww *= pos[d];
+                        pl[d] = pg[d] + 1;
+                    } else {
+                        ww *= 1 - pos[d];
+                        pl[d] = pg[d];
+                    }
+                }
+                const uint32_t idx = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pl[0], pl[1], pl[2]);
+                float v[1] = {ww * gc};
+                if (nlr_run_merge<1>(idx, v, valid, lane)) atomicAdd(&acc[idx], v[0]);
+            }
+        }
+    } else
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const uint32_t b = t / C, ch = t % C;
         const float x0 = x[(size_t)b * 3 + 0], x1 = x[(size_t)b * 3 + 1], x2 = x[(size_t)b * 3 + 2];
@@ -336,6 +376,193 @@ __global__ void __launch_bounds__(1024) nlr_grid_bwd_lds_kernel(const float *__r
     }
 }
 
+// =====================================================================================================================================
+// Binned scatter (round 4).  The atomic kernels above end at the memory side's rate for scattered float atomics
+// (~27 G/s measured: 5.5e8 atomics of a 29.4 M-point proposal-grid backward in 20 ms).  Every level that does not fit the LDS copy of
+// nlr_grid_bwd_lds_kernel is cut into BUCKETS of 32 768 floats (128 KiB of its table), and the scatter becomes two streaming passes:
+//   pass 1 (nlr_grid_bwd_bin_kernel): a workgroup takes a chunk of NLR_BIN_CHUNK consecutive points of one level, computes their corner
+//     updates (runs of equal entries inside a 16-lane row merged as in nlr_run_atomic), counts them per bucket in LDS, scans, and
+//     writes them bucket by bucket into the chunk's own region of the workspace: items = (entry index inside the bucket, C values).
+//     Per (level, bucket, chunk) it leaves a start and a count.  No global atomics, coalesced-by-bucket writes.
+//   pass 2 (nlr_grid_bwd_acc_kernel): NLR_BIN_SPLIT workgroups per bucket walk the chunks' segments of THEIR bucket, add them into an
+//     LDS image of the bucket (ds_add_f32) and add the image to the table once, with coalesced atomics on consecutive addresses.
+// Global atomics per level drop from (points x 8 corners / run length) scattered ones to (bucket floats x NLR_BIN_SPLIT) coalesced ones;
+// the price is the item stream through HBM (8 + 4 C bytes written and read per merged corner update).
+// =====================================================================================================================================
+#define NLR_BIN_FLOATS 32768u   // floats of table per bucket (128 KiB of LDS in pass 2)
+#define NLR_BIN_CHUNK 8192u     // points per pass-1 workgroup (segments of ~1 000 items per bucket: pass 2 reads them in long runs)
+#define NLR_BIN_SPLIT 16u       // pass-2 workgroups per bucket (a dense level concentrates its items in the few buckets the scene occupies)
+#define NLR_BIN_MAXB 256u       // buckets per level at most (2^21 entries x 4 channels)
+
+struct BinArgs {
+    uint32_t nlev;             // levels that go through the bins
+    uint32_t level[NLR_MAX_GRID_LEVELS];
+    uint32_t nb[NLR_MAX_GRID_LEVELS];   // buckets of that level
+    uint32_t nchunks, shift;   // entry index >> shift = bucket
+    uint32_t *counts, *starts; // [nlev][NLR_BIN_MAXB][nchunks]
+    uint32_t *item_idx;        // [nlev][nchunks][NLR_BIN_CHUNK * 8]
+    float *item_val;           // [nlev][nchunks][NLR_BIN_CHUNK * 8][C]
+};
+
+template <int C>
+__global__ void __launch_bounds__(256) nlr_grid_bwd_bin_kernel(const float *__restrict__ grad, const float *__restrict__ x, GridParams gp,
+                                                               uint32_t B, int grad_layout, BinArgs a) {
+    __shared__ uint32_t cnt[NLR_BIN_MAXB], cur[NLR_BIN_MAXB];
+    const uint32_t chunk = blockIdx.x, li = blockIdx.y, level = a.level[li], nb = a.nb[li];
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i = threadIdx.x; i < NLR_BIN_MAXB; i += 256) cnt[i] = 0;
+    __syncthreads();
+    const uint32_t hsize = gp.hsize[level], res = gp.res[level];
+    const float scale = gp.scale[level];
+    const float half = gp.align_corners ? 0.0f : 0.5f;
+    const size_t region = ((size_t)li * a.nchunks + chunk) * (NLR_BIN_CHUNK * 8);
+    const uint32_t emask = (1u << a.shift) - 1u;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t it = 0; it < NLR_BIN_CHUNK; it += 256) {
+            const uint32_t b0 = chunk * NLR_BIN_CHUNK + it + threadIdx.x;
+            const bool inb = b0 < B;
+            const uint32_t b = inb ? b0 : B - 1;
+            const float x0 = x[(size_t)b * 3 + 0], x1 = x[(size_t)b * 3 + 1], x2 = x[(size_t)b * 3 + 2];
+            const bool valid = inb && !((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
+            float g[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                g[c] = grad_layout == 0 ? grad[((size_t)level * B + b) * C + c] : grad[(size_t)b * gp.L * C + level * C + c];
+            float pos[3] = {fmaf(valid ? x0 : 0.5f, scale, half), fmaf(valid ? x1 : 0.5f, scale, half), fmaf(valid ? x2 : 0.5f, scale, half)};
+            uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                pg[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pg[d];
+                if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+            }
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                float ww = 1.0f;
+                uint32_t pl[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    if ((c8 >> d) & 1) {
+                        ww *= pos[d];
+                        pl[d] = pg[d] + 1;
+                    } else {
+                        ww *= 1 - pos[d];
+                        pl[d] = pg[d];
+                    }
+                }
+                const uint32_t idx = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pl[0], pl[1], pl[2]);
+                float v[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[c] = ww * g[c];
+                if (nlr_run_merge<C>(idx, v, valid, lane)) {
+                    const uint32_t bucket = idx >> a.shift;
+                    if (pass == 0) {
+                        atomicAdd(&cnt[bucket], 1u);
+                    } else {
+                        const size_t p = region + atomicAdd(&cur[bucket], 1u);
+                        a.item_idx[p] = idx & emask;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) a.item_val[p * C + c] = v[c];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (threadIdx.x == 0) {
+                uint32_t run = 0;
+                for (uint32_t i = 0; i < nb; ++i) {
+                    cur[i] = run;
+                    run += cnt[i];
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < nb; i += 256) {
+                const size_t o = ((size_t)li * NLR_BIN_MAXB + i) * a.nchunks + chunk;
+                a.counts[o] = cnt[i];
+                a.starts[o] = cur[i];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(1024) nlr_grid_bwd_acc_kernel(GridParams gp, float *__restrict__ grad_table, BinArgs a) {
+    extern __shared__ float acc[];  // NLR_BIN_FLOATS
+    const uint32_t bucket = blockIdx.x, li = blockIdx.y, split = blockIdx.z;
+    if (bucket >= a.nb[li]) return;
+    const uint32_t level = a.level[li];
+    for (uint32_t i = threadIdx.x; i < NLR_BIN_FLOATS; i += 1024) acc[i] = 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // 16 waves per workgroup: the 128 KiB image leaves room for ONE workgroup per CU, and a segment read is a dependent chain (start /
+    // count, then items), so the loads in flight per CU are what the waves of this workgroup bring (4 waves: 8-10 ms per launch)
+    const uint32_t wave = split * 16 + (threadIdx.x >> 6), nwaves = NLR_BIN_SPLIT * 16;
+    const uint32_t *cn = a.counts + ((size_t)li * NLR_BIN_MAXB + bucket) * a.nchunks;
+    const uint32_t *st = a.starts + ((size_t)li * NLR_BIN_MAXB + bucket) * a.nchunks;
+    // a wave takes blocks of 8 consecutive chunks (one load brings their (start, count), then the segments one by one).  Small blocks: a
+    // dense level puts its items into the few buckets the scene occupies, and all NLR_BIN_SPLIT x 16 waves of such a bucket must get work
+    // (blocks of 64 chunks left 57 waves with 350 k items each and the rest idle: 7.3 ms per launch whatever else changed)
+    for (uint32_t c0 = wave * 8; c0 < a.nchunks; c0 += nwaves * 8) {
+        const uint32_t mine = c0 + (lane & 7) < a.nchunks ? c0 + (lane & 7) : a.nchunks - 1;
+        const uint32_t my_n = c0 + (lane & 7) < a.nchunks ? cn[mine] : 0u, my_s = st[mine];
+        const uint32_t lim = a.nchunks - c0 < 8 ? a.nchunks - c0 : 8;
+        for (uint32_t j = 0; j < lim; ++j) {
+            const uint32_t n = __builtin_amdgcn_readlane(my_n, j), s0 = __builtin_amdgcn_readlane(my_s, j);
+            const size_t base = ((size_t)li * a.nchunks + (c0 + j)) * (NLR_BIN_CHUNK * 8) + s0;
+            // four loads per lane in flight before the first LDS add (one at a time, the 16 waves of a CU leave the memory pipe idle)
+            for (uint32_t i = lane; i < n; i += 256) {
+                uint32_t e[4];
+                float v[4][C];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t k = i + u * 64 < n ? i + u * 64 : i;
+                    e[u] = a.item_idx[base + k];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) v[u][c] = a.item_val[(base + k) * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u * 64 < n) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) atomicAdd(&acc[e[u] * C + c], v[u][c]);
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t floats = gp.hsize[level] * C, f0 = bucket * NLR_BIN_FLOATS;
+    float *gt = grad_table + (size_t)gp.offset[level] * C + f0;
+    for (uint32_t i = threadIdx.x; i < NLR_BIN_FLOATS && f0 + i < floats; i += 1024) {
+        const float v = acc[i];
+        if (v != 0.0f) atomicAdd(gt + i, v);
+    }
+}
+
+// Which levels go through the bins, and what workspace that takes (host).
+static size_t nlr_bin_plan(const GridParams &gp, uint32_t B, uint32_t C, BinArgs *a) {
+    memset(a, 0, sizeof(*a));
+    uint32_t sh = 0;
+    while ((NLR_BIN_FLOATS / C) >> (sh + 1)) ++sh;  // log2(entries per bucket)
+    a->shift = sh;
+    a->nchunks = (B + NLR_BIN_CHUNK - 1) / NLR_BIN_CHUNK;
+    // C = 4 (the NerfMLP grid: 256 buckets per level, 20-byte items) loses against the atomics - 34.1 against 28.2 ms at 14.7 M points,
+    // profiles/r04_grid_scatter_ab.txt: its per-(chunk, bucket) segments are too short for the scattered item writes to combine - and stays there
+    if (C > 2) return 0;
+    for (uint32_t l = 0; l < gp.L; ++l) {
+        if (nlr_level_fits_lds(gp, l, C)) continue;
+        const uint32_t nb = (gp.hsize[l] + (1u << sh) - 1) >> sh;
+        if (nb > NLR_BIN_MAXB) return 0;  // (tables beyond 2^21 x 4 floats per level: atomics)
+        a->level[a->nlev] = l;
+        a->nb[a->nlev++] = nb;
+    }
+    if (!a->nlev) return 0;
+    const size_t tab = (size_t)a->nlev * NLR_BIN_MAXB * a->nchunks * sizeof(uint32_t);
+    const size_t items = (size_t)a->nlev * a->nchunks * NLR_BIN_CHUNK * 8;
+    return 2 * tab + items * sizeof(uint32_t) + items * C * sizeof(float);
+}
+
 __global__ void __launch_bounds__(256) nlr_grid_input_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ dy_dx,
                                                                  float *__restrict__ grad_inputs, uint32_t B, uint32_t L,
                                                                  uint32_t C, int grad_layout) {
@@ -352,10 +579,42 @@ __global__ void __launch_bounds__(256) nlr_grid_input_bwd_kernel(const float *__
     grad_inputs[t] = r;
 }
 
+extern "C" size_t nlr_grid_backward_workspace_bytes(uint32_t B, uint32_t C, uint32_t L, float S, uint32_t H, const int32_t *offsets_host,
+                                                    uint32_t gridtype, int align_corners) {
+    if (!offsets_host || B == 0 || !(C == 1 || C == 2 || C == 4)) return 0;
+    GridParams gp;
+    if (nlr_fill_grid_params(&gp, offsets_host /* any non-null pointer: only the level constants are read */, 0, offsets_host, L, C, S, H, gridtype,
+                             align_corners, 0))
+        return 0;
+    BinArgs a;
+    return nlr_bin_plan(gp, B, C, &a);
+}
+
+static int nlr_grid_backward_impl(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
+                                  uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs,
+                                  uint32_t gridtype, int align_corners, uint32_t interp, int grad_layout, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+
 extern "C" int nlr_grid_encode_backward(const float *grad, const float *inputs, const int32_t *offsets_host,
                                         float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                         uint32_t H, const float *dy_dx, float *grad_inputs, uint32_t gridtype,
                                         int align_corners, uint32_t interp, int grad_layout, void *stream) {
+    return nlr_grid_backward_impl(grad, inputs, offsets_host, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp,
+                                  grad_layout, nullptr, 0, stream);
+}
+
+extern "C" int nlr_grid_encode_backward_ws(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings,
+                                           uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx,
+                                           float *grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp, int grad_layout,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+    return nlr_grid_backward_impl(grad, inputs, offsets_host, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp,
+                                  grad_layout, workspace, workspace_bytes, stream);
+}
+
+static int nlr_grid_backward_impl(const float *grad, const float *inputs, const int32_t *offsets_host, float *grad_embeddings, uint32_t B,
+                                  uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs,
+                                  uint32_t gridtype, int align_corners, uint32_t interp, int grad_layout, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
     NLR_CHECK_ARG(D == 3, "GridEncoding: this build supports input_dim D = 3 only (got %u)", D);
     NLR_CHECK_ARG(grad && inputs && grad_embeddings, "grid_encode_backward: NULL tensor");
     NLR_CHECK_ARG((dy_dx == nullptr) == (grad_inputs == nullptr), "grid_encode_backward: dy_dx and grad_inputs go together");
@@ -383,13 +642,43 @@ extern "C" int nlr_grid_encode_backward(const float *grad, const float *inputs, 
         }
         NLR_LAUNCH_CHECK("nlr_grid_bwd_lds_kernel");
     }
-    switch (C) {
-        case 1: hipLaunchKernelGGL(nlr_grid_bwd_kernel<1>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
-        case 2: hipLaunchKernelGGL(nlr_grid_bwd_kernel<2>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
-        case 4: hipLaunchKernelGGL(nlr_grid_bwd_kernel<4>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
-        default: hipLaunchKernelGGL(nlr_grid_bwd_kernel<8>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
+    // the other levels: through the bins when the caller brought the workspace for it (and the LDS kernel took the small levels), else atomics
+    BinArgs ba;
+    const size_t need = (lds_levels && workspace && (C == 1 || C == 2 || C == 4)) ? nlr_bin_plan(gp, B, C, &ba) : 0;
+    if (need && workspace_bytes >= need) {
+        const size_t tab = (size_t)ba.nlev * NLR_BIN_MAXB * ba.nchunks, items = (size_t)ba.nlev * ba.nchunks * NLR_BIN_CHUNK * 8;
+        ba.counts = (uint32_t *)workspace;
+        ba.starts = ba.counts + tab;
+        ba.item_idx = ba.starts + tab;
+        ba.item_val = (float *)(ba.item_idx + items);
+        uint32_t nbmax = 0;
+        for (uint32_t i = 0; i < ba.nlev; ++i) nbmax = ba.nb[i] > nbmax ? ba.nb[i] : nbmax;
+        dim3 g1(ba.nchunks, ba.nlev), g2b(nbmax, ba.nlev, NLR_BIN_SPLIT), b1024(1024);
+        const size_t lds = NLR_BIN_FLOATS * sizeof(float);
+#define NLR_BIN_LAUNCH(CC)                                                                                                            \
+    do {                                                                                                                              \
+        hipLaunchKernelGGL(nlr_grid_bwd_bin_kernel<CC>, g1, block, 0, st, grad, inputs, gp, B, grad_layout, ba);                      \
+        static bool attr_##CC = false;                                                                                                \
+        if (!attr_##CC) {                                                                                                             \
+            (void)hipFuncSetAttribute((const void *)nlr_grid_bwd_acc_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_##CC = true;                                                                                                         \
+        }                                                                                                                             \
+        hipLaunchKernelGGL(nlr_grid_bwd_acc_kernel<CC>, g2b, b1024, lds, st, gp, grad_embeddings, ba);                                \
+    } while (0)
+        if (C == 1) NLR_BIN_LAUNCH(1);
+        else if (C == 2) NLR_BIN_LAUNCH(2);
+        else NLR_BIN_LAUNCH(4);
+#undef NLR_BIN_LAUNCH
+        NLR_LAUNCH_CHECK("nlr_grid_bwd_bin_kernel / nlr_grid_bwd_acc_kernel");
+    } else {
+        switch (C) {
+            case 1: hipLaunchKernelGGL(nlr_grid_bwd_kernel<1>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
+            case 2: hipLaunchKernelGGL(nlr_grid_bwd_kernel<2>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
+            case 4: hipLaunchKernelGGL(nlr_grid_bwd_kernel<4>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
+            default: hipLaunchKernelGGL(nlr_grid_bwd_kernel<8>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
+        }
+        NLR_LAUNCH_CHECK("nlr_grid_bwd_kernel");
     }
-    NLR_LAUNCH_CHECK("nlr_grid_bwd_kernel");
     if (dy_dx) {
         hipLaunchKernelGGL(nlr_grid_input_bwd_kernel, dim3((B * 3 + 255) / 256), block, 0, st, grad, dy_dx, grad_inputs, B, L, C,
                            grad_layout);

@@ -106,3 +106,31 @@ __device__ __forceinline__ void nlr_run_atomic(float *gt, uint32_t addr, float v
     if (valid && tail) atomicAdd(gt + addr, v);
 }
 
+// Segmented inclusive scan over runs of equal `key` inside a 16-lane row, C values per lane; true in the lane that ends a run
+// (it then holds the run's sums).  Lanes with valid = false never join a run.
+template <int C>
+__device__ __forceinline__ bool nlr_run_merge(uint32_t key, float (&v)[C], bool valid, int lane) {
+    const int r = lane & 15;
+    const uint32_t k = valid ? key : 0xffffffffu - (uint32_t)lane;
+    constexpr int SHR = 0x110, SHL = 0x100;
+    const uint32_t left = nlr_dpp_u<SHR + 1>(k);
+    uint32_t head = (r < 1 || left != k) ? 1u : 0u;
+    const uint32_t right_head = nlr_dpp_u<SHL + 1>(head);
+    const bool tail = (r >= 15) || right_head != 0u;
+#define NLR_MERGE_STEP(D)                                              \
+    {                                                                  \
+        float vo[C];                                                   \
+        _Pragma("unroll") for (int c = 0; c < C; ++c) vo[c] = nlr_dpp_f<SHR + (D)>(v[c]); \
+        const uint32_t ho = r < (D) ? 1u : nlr_dpp_u<SHR + (D)>(head); \
+        if (!head) {                                                   \
+            _Pragma("unroll") for (int c = 0; c < C; ++c) v[c] += vo[c]; \
+            head = ho;                                                 \
+        }                                                              \
+    }
+    NLR_MERGE_STEP(1)
+    NLR_MERGE_STEP(2)
+    NLR_MERGE_STEP(4)
+    NLR_MERGE_STEP(8)
+#undef NLR_MERGE_STEP
+    return valid && tail;
+}

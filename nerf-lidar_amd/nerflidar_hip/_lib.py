@@ -85,7 +85,7 @@ EXPORTS = ["nlr_last_error", "nlr_version", "nlr_build_sha", "nlr_grid_encode_fo
            "nlr_composite_backward", "nlr_hash_decay_forward", "nlr_hash_decay_backward", "nlr_box_winner", "nlr_cast_contract",
            "nlr_track_box_params", "nlr_objects_create", "nlr_objects_destroy", "nlr_objects_workspace_bytes", "nlr_objects_apply",
            "nlr_render_rays_dynamic", "nlr_prop_mlp_forward", "nlr_prop_mlp_backward", "nlr_encode_features_forward",
-           "nlr_encode_features_backward",
+           "nlr_encode_features_backward", "nlr_encode_features_backward_ws", "nlr_grid_encode_backward_ws", "nlr_grid_backward_workspace_bytes",
            "nlr_train_plan_create", "nlr_train_plan_destroy", "nlr_train_act_width", "nlr_train_param_layout", "nlr_train_pack",
            "nlr_mlp_train_forward", "nlr_mlp_train_backward"]
 NLR_K_COUNT = 6
@@ -118,6 +118,9 @@ def lib():
         L.nlr_grid_encode_backward.argtypes = [c_fp, c_fp, c_fp, c_fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.c_float, C.c_uint32, c_fp, c_fp, C.c_uint32, C.c_int, C.c_uint32,
                                                C.c_int, c_fp]
+        L.nlr_grid_encode_backward_ws.argtypes = L.nlr_grid_encode_backward.argtypes[:-1] + [c_fp, C.c_size_t, c_fp]
+        L.nlr_grid_backward_workspace_bytes.restype = C.c_size_t
+        L.nlr_grid_backward_workspace_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, c_fp, C.c_uint32, C.c_int]
         L.nlr_grad_total_variation.argtypes = [c_fp, c_fp, c_fp, c_fp, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
                                                C.c_uint32, C.c_uint32, C.c_int, c_fp]
         L.nlr_render_rays.argtypes = [c_fp, C.POINTER(NlrRays), C.c_uint32, C.POINTER(NlrRenderCfg), C.POINTER(NlrOut),
@@ -156,6 +159,7 @@ def lib():
                                                   C.POINTER(NlrGridDesc), C.c_uint32, c_fp, c_fp]
         L.nlr_encode_features_backward.argtypes = [C.POINTER(NlrRays), c_fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, c_fp,
                                                    C.POINTER(NlrGridDesc), C.c_uint32, c_fp, c_fp, c_fp, c_fp, c_fp]
+        L.nlr_encode_features_backward_ws.argtypes = L.nlr_encode_features_backward.argtypes[:-1] + [c_fp, C.c_size_t, c_fp]
         L.nlr_train_plan_create.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int] + [C.c_float] * 4 + [C.POINTER(c_fp), C.POINTER(C.c_uint32)]
         L.nlr_train_plan_destroy.restype = None
         L.nlr_train_plan_destroy.argtypes = [c_fp]

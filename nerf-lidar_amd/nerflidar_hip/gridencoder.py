@@ -74,10 +74,11 @@ class _Backend:
         _device_operand(grad_embeddings, "grad_embeddings")
         off = _host_offsets(offsets)
         with torch.cuda.device(inputs.device):
-            _lib.check(_lib.lib().nlr_grid_encode_backward(
+            ws = backward_workspace(B, C, L, S, H, off, gridtype, align_corners, inputs.device)
+            _lib.check(_lib.lib().nlr_grid_encode_backward_ws(
                 _lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(off), _lib.ptr(grad_embeddings), B, D, C, L, float(S), int(H),
                 _lib.ptr(dy_dx), _lib.ptr(grad_inputs), int(gridtype), int(bool(align_corners)), int(interp),
-                int(grad_layout), _lib.current_stream()), "grid_encode_backward")
+                int(grad_layout), _lib.ptr(ws), 0 if ws is None else ws.numel(), _lib.current_stream()), "grid_encode_backward")
 
     @staticmethod
     def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
@@ -91,6 +92,18 @@ class _Backend:
             _lib.check(_lib.lib().nlr_grad_total_variation(
                 _lib.ptr(inputs), _lib.ptr(embeddings), _lib.ptr(grad), _lib.ptr(off), float(weight), B, D, C, L, float(S), int(H),
                 int(gridtype), int(bool(align_corners)), _lib.current_stream()), "grad_total_variation")
+
+
+BINNED_SCATTER = True  # large batches scatter through bins (nlr_grid_encode_backward_ws); False: scattered atomics only (A/B, tests)
+
+
+def backward_workspace(B, C, L, S, H, offsets_host, gridtype, align_corners, device):
+    """The binned scatter's workspace for a B-point backward, or None when the batch is small / the grid outside its envelope."""
+    if not BINNED_SCATTER or B * C < (1 << 18):
+        return None
+    need = _lib.lib().nlr_grid_backward_workspace_bytes(int(B), int(C), int(L), float(S), int(H), _lib.ptr(offsets_host), int(gridtype),
+                                                        int(bool(align_corners)))
+    return torch.empty(need, dtype=torch.uint8, device=device) if need else None
 
 
 _backend = _Backend()

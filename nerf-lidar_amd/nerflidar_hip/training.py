@@ -221,10 +221,14 @@ class _EncodeFeatures(torch.autograd.Function):
         pts = torch.empty(n * S * sample_n, 3, device=tab.device)                      # scratch: unit-cube positions of the multisamples
         gpt = torch.empty(n * S * sample_n, encoder.output_dim, device=tab.device)     # scratch: their feature gradients
         rays, gd = _EncodeFeatures._descs(encoder, keep, tab)
+        from .gridencoder import backward_workspace
         with torch.cuda.device(tab.device):
-            _lib.check(_lib.lib().nlr_encode_features_backward(C.byref(rays), _lib.ptr(td), n, S, sample_n, sample_m, std_scale, _lib.ptr(rd),
-                                                               C.byref(gd), re_w, _lib.ptr(g), _lib.ptr(pts), _lib.ptr(gpt), _lib.ptr(grad),
-                                                               _lib.current_stream()), "nlr_encode_features_backward")
+            ws = backward_workspace(n * S * sample_n, tab.shape[1], encoder.num_levels, float(np.log2(encoder.per_level_scale)),
+                                    int(encoder.base_resolution), encoder._offsets_host, encoder.gridtype_id, encoder.align_corners, tab.device)
+            _lib.check(_lib.lib().nlr_encode_features_backward_ws(C.byref(rays), _lib.ptr(td), n, S, sample_n, sample_m, std_scale, _lib.ptr(rd),
+                                                                  C.byref(gd), re_w, _lib.ptr(g), _lib.ptr(pts), _lib.ptr(gpt), _lib.ptr(grad),
+                                                                  _lib.ptr(ws), 0 if ws is None else ws.numel(), _lib.current_stream()),
+                       "nlr_encode_features_backward")
         return (grad.to(tab.dtype),) + (None,) * 8
 
 
