@@ -539,17 +539,82 @@ class TrainablePropLevel(torch.nn.Module):
         return {"density": torch.nn.functional.softplus(raw + self.cfg.density_bias)}
 
 
+class TrainableObjMLP(torch.nn.Module):
+    """One class's object network (ZI/models.py:MLP as `ObjMLP` configures it under the shipped gin, nuscenes_single.gin:36-44) as a
+    trainable module with the reference's parameter names (`encoder.embeddings`, `density_layer.{0,2}`, `lin_second_stage_{i}`,
+    `rgb_layer`): hash grid on box coordinates through the HIP operator (forward + backward), [grid | shape half of the latent] -> 64 ->
+    bottleneck, view MLP on [bottleneck | pos_enc(dir) | texture half] with the skip concatenation, fixed one-hot semantic of the class.
+    The differentiable twin of `objects.ObjMLP.forward`."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        from .gridencoder import GridEncoder
+        from .weights import mlp_param_shapes
+        nn = torch.nn
+        self.cfg = cfg
+        self.encoder = GridEncoder(input_dim=3, num_levels=cfg.grid_num_levels, level_dim=cfg.grid_level_dim,
+                                   base_resolution=cfg.grid_base_resolution, desired_resolution=cfg.grid_disired_resolution,
+                                   log2_hashmap_size=cfg.grid_log2_hashmap_size, gridtype="hash", align_corners=False)
+        for name, (o, i), kaiming in mlp_param_shapes(cfg):
+            lin = nn.Linear(i, o)
+            if kaiming:
+                nn.init.kaiming_uniform_(lin.weight)
+            mod, _, leaf = name.partition(".")
+            if leaf:  # density_layer.0 / .2: an nn.Sequential with a ReLU between, like the reference's
+                if not hasattr(self, mod):
+                    self.add_module(mod, nn.Sequential())
+                seq = getattr(self, mod)
+                while len(seq) < int(leaf):
+                    seq.append(nn.ReLU())
+                seq.append(lin)
+            else:
+                self.add_module(name, lin)
+
+    load_reference = TrainableNerfLevel.load_reference
+
+    def forward(self, pts: torch.Tensor, viewdirs: torch.Tensor, latent: Optional[torch.Tensor]) -> Dict[str, torch.Tensor]:
+        from .objects import _pos_enc
+        F = torch.nn.functional
+        cfg = self.cfg
+        feats = self.encoder(pts.contiguous(), bound=1)
+        if latent is not None:
+            feats = torch.cat([feats, latent[:, : cfg.latent_size // 2] if cfg.split_latent else latent], dim=-1)
+        x = self.density_layer(feats)
+        out = {"density": F.softplus(x[..., 0] + cfg.density_bias)}
+        if cfg.use_semantic:
+            sem = torch.zeros(x.shape[0], cfg.class_num, device=x.device)
+            if cfg.class_type != 255:
+                sem[:, cfg.class_type] = 1.0
+            out["semantic"] = sem
+        h = [x, _pos_enc(viewdirs, cfg.deg_view)]
+        if cfg.split_latent:
+            h.append(latent[:, cfg.latent_size // 2:])
+        h = torch.cat(h, dim=-1)
+        inputs = h
+        for i in range(cfg.net_depth_viewdirs):
+            h = F.relu(getattr(self, f"lin_second_stage_{i}")(h))
+            if i == cfg.skip_layer_dir:
+                h = torch.cat([h, inputs], dim=-1)
+        rgb = torch.sigmoid(cfg.rgb_premultiplier * self.rgb_layer(h) + cfg.rgb_bias)
+        out["rgb"] = rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
+        return out
+
+
 class TrainableModel(torch.nn.Module):
-    """`Model` (ZI/models.py:31-576, instance_obj = False, no GLO) as a trainable module: submodules `prop_mlp_<i>` and
-    `nerf_mlp` with the reference's parameter names, so a reference checkpoint loads with `load_reference` and the trained
-    `state_dict()` goes straight into `nerflidar_hip.models.Model` for fused inference.
+    """`Model` (ZI/models.py:31-576, no GLO) as a trainable module: submodules `prop_mlp_<i>` and `nerf_mlp` with the reference's
+    parameter names, so a reference checkpoint loads with `load_reference` and the trained `state_dict()` goes straight into
+    `nerflidar_hip.models.Model` for fused inference.  With `mc.config.instance_obj` (the shipped gin, nuscenes_single.gin:13) and
+    `tracks` / `class_names` also the dynamic-object branch of models.py:401-477 in training form: `obj_mlp_<class id>` per class,
+    `latent_vector_dict.obj_latent_<track>` per track (train_utils.py:459-471), evaluated on the samples inside the boxes of every level
+    (detached on the proposal levels, models.py:447-449) and merged before compositing; `obj_mask` rides in the ray history for the
+    interlevel term (train_utils.py:153-157).  Its `state_dict()` feeds `objects.DynamicModel` / `checkpoints.dynamic_model_from_checkpoint`.
 
     forward = the level loop of models.py:316-557 in training form: the sample positions come from the fused resampling kernel
     (`nlr_resample_level`; they carry no gradient, Model.stop_level_grad = True), cast / contraction from `nlr_cast_contract`,
     hash-grid features and their gradient from the HIP grid operator, the NerfMLP from torch Linear modules or the fused MFMA
     forward / backward (`fused_mlp=True`), compositing and its gradient from `nlr_composite_level` / `nlr_composite_backward`."""
 
-    def __init__(self, mc, fused_mlp: bool = False):
+    def __init__(self, mc, fused_mlp: bool = False, tracks=None, class_names=None, obj_log2_hashmap: int = 21):
         super().__init__()
         self.mc = mc
         for i in range(mc.num_levels - 1):
@@ -558,6 +623,27 @@ class TrainableModel(torch.nn.Module):
         ncfg = dataclasses.replace(mc.nerf_mlp, use_semantic=mc.config.use_semantic, use_intensity=mc.config.use_intensity,
                                    no_sem_layer=mc.config.no_sem_layer)
         self.nerf_mlp = TrainableNerfLevel(ncfg, fused_mlp=fused_mlp)
+        self.instance_obj = bool(mc.config.instance_obj)
+        if self.instance_obj:
+            from .config import obj_mlp_config
+            from .objects import query_class
+            if tracks is None or class_names is None:
+                raise ValueError("Config.instance_obj = True needs tracks [N_obj, T, 9] and one class name per track (dataset.bboxes)")
+            if mc.config.use_intensity:
+                raise NotImplementedError("instance_obj with use_intensity: ObjMLP has no intensity head and the reference's merge assigns "
+                                          "None into the intensity tensor (ZI/models.py:469) - not a runnable configuration")
+            if mc.config.latent_size <= 0:
+                raise NotImplementedError("per-instance ObjMLPs (Config.latent_size = 0) are not a runnable configuration under the shipped "
+                                          "gin (ObjMLP.split_latent = True indexes latent = None, ZI/models.py:1201-1203)")
+            self.register_buffer("tracks", torch.as_tensor(np.asarray(tracks, np.float32)))
+            self.class_ids = [query_class(c) for c in class_names]
+            self._class_list = sorted(set(self.class_ids))
+            self.register_buffer("_class_rank", torch.tensor([self._class_list.index(c) for c in self.class_ids]))
+            for cid in self._class_list:
+                self.add_module(f"obj_mlp_{cid}", TrainableObjMLP(obj_mlp_config(cid, latent_size=mc.config.latent_size, log2_hashmap=obj_log2_hashmap,
+                                                                                 use_semantic=mc.config.use_semantic)))
+            self.latent_vector_dict = torch.nn.ParameterDict(
+                {f"obj_latent_{t}": torch.nn.Parameter(torch.nn.init.normal_(torch.empty(mc.config.latent_size))) for t in range(len(self.class_ids))})
 
     def levels(self):
         return [getattr(self, f"prop_mlp_{i}") for i in range(self.mc.num_levels - 1)] + [self.nerf_mlp]
@@ -566,14 +652,78 @@ class TrainableModel(torch.nn.Module):
         for i in range(self.mc.num_levels - 1):
             getattr(self, f"prop_mlp_{i}").load_reference(state_dict, f"prop_mlp_{i}.")
         self.nerf_mlp.load_reference(state_dict, "nerf_mlp.")
+        if self.instance_obj:
+            for cid in self._class_list:
+                getattr(self, f"obj_mlp_{cid}").load_reference(state_dict, f"obj_mlp_{cid}.")
+            with torch.no_grad():
+                for t in range(len(self.class_ids)):
+                    v = state_dict[f"latent_vector_dict.obj_latent_{t}"]
+                    self.latent_vector_dict[f"obj_latent_{t}"].copy_(v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v)))
         return self
 
     def reference_state_dict(self) -> Dict[str, np.ndarray]:
-        """Parameters under the reference's names (what `Model(mc, sd)` and `checkpoints.save_checkpoint` take)."""
-        return {k: v.detach().cpu().numpy() for k, v in self.state_dict().items() if not k.endswith(("encoder.offsets", "encoder.grid_sizes", "encoder.idx"))}
+        """Parameters under the reference's names (what `Model(mc, sd)` / `DynamicModel` and `checkpoints.save_checkpoint` take)."""
+        skip = ("encoder.offsets", "encoder.grid_sizes", "encoder.idx", "tracks", "_class_rank")
+        return {k: v.detach().cpu().numpy() for k, v in self.state_dict().items() if not k.endswith(skip)}
+
+    def latent_reg(self, latent_reg: float = 0.001) -> torch.Tensor:
+        """train.py:395-399 + train_utils.latentReg (:456-457): sum over the tracks of latent_reg * ||code||.  (sic) the reference
+        builds it with `torch.tensor([...])` from Python floats: a VALUE in the loss dictionary that carries no gradient - reproduced."""
+        z = [p.detach().norm() for p in self.latent_vector_dict.values()]
+        return latent_reg * torch.stack(z).sum()
+
+    # -- dynamic objects (models.py:401-477) --------------------------------------------------------------------------------------
+    def _object_merge(self, o: Dict[str, torch.Tensor], rgbs: torch.Tensor, batch, tdist: torch.Tensor, box: torch.Tensor, last: bool):
+        """Overwrite density / rgb / semantic of the samples inside the tracks' boxes with their ObjMLP's output.  Returns
+        (density, rgbs, semantic, obj_mask).  Owner of a sample = the last track whose box holds the interval midpoint
+        (`nlr_box_winner`; the reference's track loop overwrites earlier tracks).  Sample positions carry no gradient."""
+        n, S = tdist.shape[0], tdist.shape[1] - 1
+        dev = tdist.device
+        origins = batch["origins"].reshape(n, 3).contiguous().float()
+        dirs = batch["directions"].reshape(n, 3).contiguous().float()
+        viewdirs = batch["viewdirs"].reshape(n, 3).contiguous().float()
+        winner = torch.empty(n, S, dtype=torch.int32, device=dev)
+        td = tdist.detach().contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nlr_box_winner(_lib.ptr(td), _lib.ptr(origins), _lib.ptr(dirs), _lib.ptr(box), n, S, int(box.shape[1]),
+                                                 _lib.ptr(winner), _lib.current_stream()), "nlr_box_winner")
+        mask = winner >= 0
+        density, sem = o["density"], o.get("semantic") if last else None
+        sel = mask.nonzero()
+        if sel.shape[0] == 0:
+            return density, rgbs, sem, mask
+        ri, si = sel[:, 0], sel[:, 1]
+        tr = winner[ri, si].long()
+        bp = box[ri, tr]                                   # cos, sin, t_w_o (3), scale (3): obj_utils.py:158-176
+        t_mid = 0.5 * (td[ri, si] + td[ri, si + 1])
+        pw = t_mid[:, None] * dirs[ri] + origins[ri]
+        cs, sn = bp[:, 0], bp[:, 1]
+        rx = cs * pw[:, 0] - sn * pw[:, 1]
+        p_all = bp[:, 5:8] * (torch.stack([rx, sn * rx + cs * pw[:, 1], pw[:, 2]], dim=-1) + bp[:, 2:5])
+        vd = viewdirs[ri]
+        vx = cs * vd[:, 0] - sn * vd[:, 1]
+        d_all = bp[:, 5:8] * torch.stack([vx, sn * vx + cs * vd[:, 1], vd[:, 2]], dim=-1)
+        d_all = d_all / torch.norm(d_all, dim=-1, keepdim=True)
+        table = torch.stack([self.latent_vector_dict[f"obj_latent_{t}"] for t in range(len(self.class_ids))])
+        lat_all = table[tr]
+        rank = self._class_rank[tr]
+        density, rgbs = density.clone(), rgbs.clone()
+        sem = sem.clone() if sem is not None else None
+        for r_, cid in enumerate(self._class_list):
+            pick = (rank == r_).nonzero()[:, 0]
+            if pick.numel() == 0:
+                continue
+            res = getattr(self, f"obj_mlp_{cid}")(p_all[pick], d_all[pick], lat_all[pick])
+            if not last:                                   # models.py:447-449: no gradient into the object networks from proposal levels
+                res = {k: v.detach() for k, v in res.items()}
+            density[ri[pick], si[pick]] = res["density"]
+            rgbs[ri[pick], si[pick]] = res["rgb"]
+            if sem is not None and "semantic" in res:
+                sem[ri[pick], si[pick]] = res["semantic"]
+        return density, rgbs, sem, mask
 
     def forward(self, batch: Dict[str, torch.Tensor], train_frac: float = 1.0, rand: Optional[torch.Generator] = None, randomized: bool = False,
-                sample_n: int = 7, sample_m: int = 3):
+                sample_n: int = 7, sample_m: int = 3, curr_track=None):
         """-> (renderings, ray_history), one entry per level, like `Model.forward`.  randomized (or a generator in `rand`): per-ray
         jitter of the sample positions (stepfun.py:216) and per-multisample rotation (render.py:150), as `model(True, ...)` draws
         them in train.py:272."""
@@ -588,6 +738,16 @@ class TrainableModel(torch.nn.Module):
         n_prev, prod = 0, 1.0
         renderings, history = [], []
         samples = mc.level_samples()
+        box = None
+        if self.instance_obj:
+            if "timestamp" not in batch:
+                raise RuntimeError("batch['timestamp'] is missing (ZI/models.py:315)")
+            tracks = (self.tracks if curr_track is None else torch.as_tensor(curr_track, device=dev, dtype=torch.float32)).contiguous()
+            ts = batch["timestamp"].reshape(-1).to(dev, torch.float32).contiguous()
+            box = torch.empty(n, tracks.shape[0], 8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.nlr_track_box_params(_lib.ptr(tracks), _lib.ptr(ts), n, tracks.shape[0], tracks.shape[1], _lib.ptr(box),
+                                                  _lib.current_stream()), "nlr_track_box_params")
         for li, (S, level) in enumerate(zip(samples, self.levels())):
             last = li == len(samples) - 1
             use_dil = mc.dilation_bias > 0 or mc.dilation_multiplier > 0                      # models.py:322-346
@@ -603,6 +763,12 @@ class TrainableModel(torch.nn.Module):
             rd = torch.rand(n, S, sample_n, device=dev, generator=rand) if randomized else None
             o = level(batch, tdist, sample_n, sample_m, rand_deg=rd)
             rgbs = o["rgb"] if last else torch.zeros(n, S, 3, device=dev)   # a PropMLP renders black (models.py:1119-1122)
+            obj_mask = None
+            if box is not None:
+                dens_m, rgbs, sem_m, obj_mask = self._object_merge(o, rgbs, batch, tdist, box, last)
+                o = dict(o, density=dens_m)
+                if sem_m is not None:
+                    o["semantic"] = sem_m
             # background colour (models.py:488-500): the range's value if it is a point, its midpoint for a deterministic render,
             # otherwise one uniform draw per ray and channel - composited here (the kernel's background is a scalar)
             lo_bg, hi_bg = mc.bg_intensity_range
@@ -620,6 +786,8 @@ class TrainableModel(torch.nn.Module):
             weights = r.pop("weights")
             renderings.append(r)
             history.append(dict(sdist=sdist, tdist=tdist, weights=weights, density=o["density"]))
+            if obj_mask is not None:
+                history[-1]["obj_mask"] = obj_mask
             prev_s, prev_w, n_prev = sdist, weights.detach().contiguous(), S
         return renderings, history
 
@@ -655,7 +823,7 @@ def create_optimizer(model: torch.nn.Module, lr_init: float = 0.01, lr_final: fl
 
 def training_step(model: TrainableModel, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], train_frac: float = 1.0,
                   randomized: bool = True, hash_decay_mult: float = 0.1, tv_weight: float = 0.0, grad_max_norm: float = 0.0,
-                  grad_max_val: float = 0.0, **loss_kw) -> Dict[str, float]:
+                  grad_max_val: float = 0.0, latent_reg: float = 0.001, **loss_kw) -> Dict[str, float]:
     """One optimiser step as train.py:272-459 takes it: forward with random jitter, the loss dictionary (`losses.total_loss` +
     hash decay), backward through the HIP backward kernels, optional total-variation gradient on the tables (grid.py:176-198),
     gradient clipping incl. the unconditional nan_to_num_ (train_utils.clip_gradients), step.  Returns the loss terms as floats."""
@@ -663,8 +831,10 @@ def training_step(model: TrainableModel, optimizer: torch.optim.Optimizer, batch
     optimizer.zero_grad(set_to_none=True)
     renderings, history = model(batch, train_frac=train_frac, randomized=randomized)
     terms = nlosses.total_loss(renderings, history, batch, **loss_kw)
-    if hash_decay_mult > 0:
+    if hash_decay_mult > 0:  # (Config.obj_nodecay, nuscenes_single.gin:24: the object grids stay out)
         terms["hash_decay"] = hash_decay_loss([lv.encoder for lv in model.levels()], hash_decay_mult)
+    if getattr(model, "instance_obj", False):
+        terms["latent_reg"] = model.latent_reg(latent_reg)
     loss = sum(terms.values())
     loss.backward()
     if tv_weight > 0:

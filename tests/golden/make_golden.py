@@ -432,9 +432,9 @@ def gen_composite_grad():
              g_intensity=gi, weights=w.detach(), **{"out_" + k: r[k].detach() for k in ("rgb", "depth", "semantic", "intensity", "acc")})
 
 
-def _build_obj_model():
+def _build_obj_model(train=False):
     """The reference `Model` with Config.instance_obj=True (latent mode, shipped ObjMLP gin bindings) on a sweep with three synthetic
-    tracks, filled with the synthetic state dict."""
+    tracks, filled with the synthetic state dict.  train: grid encoders with autograd (RefGridEncoderTrain), model left in train mode."""
     from internal import obj_utils as robj
     from nerflidar_hip import objects as nobj
     lg, width, seed = 12, 16, 2
@@ -464,9 +464,14 @@ def _build_obj_model():
                                    vis_num_rays=c.vis_num_rays, hash_decay_mults=0, symmetrize=False, latent_size=128, fuse_render=False)
     bboxes = ({i: tracks[i] for i in range(len(names))}, {i: names[i] for i in range(len(names))})
     latents = {f"obj_latent_{i}": nn.Parameter(torch.from_numpy(sd_np[f"latent_vector_dict.obj_latent_{i}"])) for i in range(len(names))}
-    model = rmodels.Model(config=cfg_ns, raydist_fn=mc.raydist_fn, opaque_background=mc.opaque_background,
-                          num_prop_samples=tuple(mc.num_prop_samples), num_nerf_samples=mc.num_nerf_samples, num_levels=mc.num_levels,
-                          prop_desired_grid_size=list(mc.prop_desired_grid_size), bboxes=bboxes, latent_vector_dict=latents)
+    if train:
+        rmodels.GridEncoder = RefGridEncoderTrain
+    try:
+        model = rmodels.Model(config=cfg_ns, raydist_fn=mc.raydist_fn, opaque_background=mc.opaque_background,
+                              num_prop_samples=tuple(mc.num_prop_samples), num_nerf_samples=mc.num_nerf_samples, num_levels=mc.num_levels,
+                              prop_desired_grid_size=list(mc.prop_desired_grid_size), bboxes=bboxes, latent_vector_dict=latents)
+    finally:
+        rmodels.GridEncoder = RefGridEncoder
     ref_sd = model.state_dict()
     new_sd = {}
     for k, v in ref_sd.items():
@@ -478,7 +483,7 @@ def _build_obj_model():
         new_sd[k] = t.to(v.dtype)
     assert not (set(sd_np) - set(ref_sd)), set(sd_np) - set(ref_sd)
     model.load_state_dict(new_sd, strict=False)
-    model.eval()
+    model.train() if train else model.eval()
     batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
     return model, batch, batch_np, tracks, cids, lg, seed, width, beams
 
@@ -848,6 +853,90 @@ def gen_train_step():
     save("fn_nusc_masks", train_py_lines=np.array([m0 + 1, m1 + 1]), **mout)
 
 
+def gen_train_step_obj():
+    """Row f-1 x f-3: the training step of the SHIPPED configuration, `Config.instance_obj = True`
+    (nuscenes_single.gin:13): the reference's `model(...)` in training mode with the dynamic-object branch (models.py:401-477: ObjMLPs on
+    the samples inside the boxes, detached on the proposal levels, latent codes per track), then lines 283-453 of train.py executed from the
+    reference's file (mask logic with instance_obj, latent regulariser, obj_mask in the interlevel term), `.backward()`.  Stored: loss
+    terms, the gradients of ObjMLP parameters, of the latent codes and of static parameters."""
+    print("training-step fixture with dynamic objects")
+    import tempfile
+    import textwrap
+    for name in ("rawpy", "mediapy", "imageio", "tensorboardX", "plyfile", "trimesh", "nuscenes"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                _stub(name)
+    _stub("pycolmap", SceneManager=object)
+    for _ in range(20):
+        try:
+            from internal import train_utils as rtu, configs as rcfg
+            break
+        except ModuleNotFoundError as e:
+            _stub(e.name)
+    model, batch, batch_np, tracks, cids, lg, seed, width, beams = _build_obj_model(train=True)
+    N = batch_np["origins"].shape[0]
+    sup = dict(rgb=rnd(90, 1, (N, 3)), depth=rnd(90, 2, (N,), 0.05, 0.4), semantic=(rnd(90, 4, (N,)) * 19).floor().clamp(0, 18),
+               mask=(rnd(90, 5, (N,)) > 0.7).float(), patch_mask=torch.zeros(N), lidar_mask=(rnd(90, 6, (N,)) > 0.5).float())
+    sup["semantic"][::7] = 255
+    sup["depth"][1::9] = 0.0
+    batch.update({k: v.clone() for k, v in sup.items()})
+    config = rcfg.Config()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "depth"))
+    open(os.path.join(tmp, "depth", "x"), "w").write("1")
+    config.data_dir, config.dataset_loader, config.patch_size = tmp, "nusc", 1
+    config.lidar_supervision, config.only_lidar_supervison, config.pose_refine = True, False, False
+    config.use_semantic, config.use_intensity, config.instance_obj, config.latent_size = True, False, True, 128
+    config.hash_decay_mults, config.symmetrize = 0.0, False
+    train_frac, step = 0.61, 9
+    renderings, ray_history = model(False, batch, train_frac=train_frac, compute_extras=True, sample_n=7, sample_m=3, zero_glo=False,
+                                    step=step, max_step=25000, curr_track=None)
+    assert all(int(h["obj_mask"].sum()) > 0 for h in ray_history)
+    src = open(os.path.join(REF, "train.py")).read().split("\n")
+    first = next(i for i, l in enumerate(src) if l.strip() == "losses = {}")
+    last = next(i for i, l in enumerate(src) if l.strip() == "loss = sum(losses.values())")
+    block = textwrap.dedent("\n".join(src[first:last + 1]))
+    ns = dict(torch=torch, nn=nn, os=os, train_utils=rtu, config=config, batch=batch, renderings=renderings, ray_history=ray_history,
+              model=model, module=model, step=step, start_step=config.start_step, end_step=config.end_step,
+              latent_vector_dict=model.latent_vector_dict)
+    exec(compile(block, "train.py[%d:%d]" % (first + 1, last + 1), "exec"), ns)
+    losses, loss = ns["losses"], ns["loss"]
+    loss.backward()
+    for p_ in model.parameters():
+        if p_.grad is not None:
+            p_.grad.nan_to_num_()
+    out = dict(log2_hashmap=np.array(lg), seed=np.array(seed), width=np.array(width), beams=np.array(beams), tracks=tracks,
+               class_ids=np.array(cids), timestamp=batch_np["timestamp"], train_frac=np.float32(train_frac), loss=loss.detach(),
+               train_py_lines=np.array([first + 1, last + 1]), latent_reg=np.float32(config.latent_reg), mask_rgb=batch["mask_rgb"])
+    for k, v in losses.items():
+        out["loss_" + k] = v.detach()
+    for k, v in sup.items():
+        out["sup_" + k] = v
+    for lvl, h in enumerate(ray_history):
+        out[f"hist{lvl}_obj_mask"] = h["obj_mask"]
+    out["out_depth"], out["out_rgb"] = renderings[-1]["depth"].detach(), renderings[-1]["rgb"].detach()
+    named = dict(model.named_parameters())
+    cid = cids[0]
+    keys = [f"obj_mlp_{cid}.density_layer.0.weight", f"obj_mlp_{cid}.rgb_layer.weight", f"obj_mlp_{cid}.lin_second_stage_0.weight",
+            f"obj_mlp_{cid}.encoder.embeddings", "nerf_mlp.density_layer.0.weight", "nerf_mlp.rgb_layer.weight", "nerf_mlp.encoder.embeddings",
+            "prop_mlp_0.density_layer.0.weight", "prop_mlp_1.encoder.embeddings"]
+    for k in keys:
+        g = named[k].grad
+        assert g is not None and float(g.abs().sum()) > 0, k
+        out["grad_" + k] = g
+    lat = []
+    for t in range(len(cids)):
+        g = model.latent_vector_dict[f"obj_latent_{t}"].grad
+        lat.append(torch.zeros(128) if g is None else g)
+    out["grad_latents"] = torch.stack(lat)
+    assert float(out["grad_latents"].abs().sum()) > 0
+    print("   loss terms:", {k: float(v.detach()) for k, v in losses.items()}, "total", float(loss.detach()),
+          "owned samples per level:", [int(h["obj_mask"].sum()) for h in ray_history])
+    save("train_step_OBJ", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -859,6 +948,9 @@ if __name__ == "__main__":
         raise SystemExit(0)
     if os.environ.get("NLR_GOLDEN_ONLY") == "obj_probe":
         probe_obj_rendering()
+        raise SystemExit(0)
+    if os.environ.get("NLR_GOLDEN_ONLY") == "train_step_obj":
+        gen_train_step_obj()
         raise SystemExit(0)
     if os.environ.get("NLR_GOLDEN_ONLY") == "train_step":
         gen_train_step()
@@ -886,5 +978,6 @@ if __name__ == "__main__":
     gen_checkpoint()
     gen_losses()
     gen_train_step()
+    gen_train_step_obj()
     gen_trained()
     print("done")

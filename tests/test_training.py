@@ -495,6 +495,72 @@ def test_whole_training_step_matches_the_reference_step(fused):
 
 
 @pytest.mark.gpu
+def test_whole_training_step_with_dynamic_objects_matches_the_reference_step():
+    """The SHIPPED configuration's step (`Config.instance_obj = True`, nuscenes_single.gin:13): the reference's
+    `model(...)` in training mode with the dynamic-object branch (models.py:401-477), train.py:283-453 executed from the reference's file
+    (mask logic with instance_obj, `latent_reg`, `obj_mask` in the interlevel term), `.backward()` - tests/golden/make_golden.py:
+    gen_train_step_obj - against `TrainableModel(mc, tracks=, class_names=)`: every loss term to 2e-4, the owner maps of all three levels
+    exactly, and the gradients of ObjMLP parameters (trunk, view MLP, rgb layer, hash table), of the latent codes of all tracks and of
+    static parameters to 5e-3 of their norm (unfused torch Linear stacks on the HIP operators)."""
+    from nerflidar_hip import losses as nl, weights as nweights, lidar as nlidar2, config as ncfg
+    g = golden("train_step_OBJ")
+    lg, seed = int(g["log2_hashmap"]), int(g["seed"])
+    mc = ncfg.workload("REF", lg)
+    mc.config.instance_obj, mc.config.latent_size = True, 128
+    mc.__post_init__()
+    names = {13: "vehicle.car", 14: "vehicle.truck", 15: "vehicle.bus.rigid", 11: "human.pedestrian.adult"}
+    class_names = [names[int(c)] for c in g["class_ids"]]
+    sd = nweights.synth_state_dict(mc, seed=seed, trained_like=True)
+    cids = sorted(set(int(c) for c in g["class_ids"]))
+    sd.update(nweights.synth_object_state_dict({c: ncfg.obj_mlp_config(c, latent_size=128, log2_hashmap=lg) for c in cids}, len(class_names), seed=seed))
+    b = nlidar2.synthetic_sweep(width=int(g["width"]), seed=seed, beams=list(g["beams"]))
+    batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    batch["timestamp"] = torch.from_numpy(g["timestamp"]).cuda()
+    for k in ("rgb", "depth", "semantic", "mask", "patch_mask", "lidar_mask"):
+        batch[k] = torch.from_numpy(g["sup_" + k]).cuda()
+    masks = nl.nusc_masks(batch, lidar_supervision=True, instance_obj=True)
+    assert torch.equal(masks["mask_rgb"].cpu(), torch.from_numpy(g["mask_rgb"]))
+    batch.update(masks)
+    tm = ntrain.TrainableModel(mc, tracks=g["tracks"], class_names=class_names, obj_log2_hashmap=lg).cuda().load_reference(sd)
+    rend, hist = tm(batch, train_frac=float(g["train_frac"]), randomized=False)
+    for lvl, h in enumerate(hist):
+        assert torch.equal(h["obj_mask"].cpu(), torch.from_numpy(g[f"hist{lvl}_obj_mask"])), f"owner map of level {lvl}"
+    terms = nl.total_loss(rend, hist, batch, depth_lam=0.1, sem_lam=0.01)          # defaults = configs.py, as the fixture's Config()
+    terms["latent_reg"] = tm.latent_reg(float(g["latent_reg"]))
+    loss = sum(terms.values())
+    loss.backward()
+    ntrain.clip_gradients(tm)
+    assert set(terms) == {k[5:] for k in g if k.startswith("loss_")}, (sorted(terms), [k for k in g if k.startswith("loss_")])
+    for k, v in terms.items():
+        np.testing.assert_allclose(float(v.detach()), float(g["loss_" + k]), rtol=2e-4, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=2e-4)
+    np.testing.assert_allclose(rend[-1]["depth"].detach().cpu().numpy(), g["out_depth"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(rend[-1]["rgb"].detach().cpu().numpy(), g["out_rgb"], atol=2e-4, rtol=0)
+    named = dict(tm.named_parameters())
+    report = []
+    got_lat = torch.stack([torch.zeros(128) if named[f"latent_vector_dict.obj_latent_{t}"].grad is None else
+                           named[f"latent_vector_dict.obj_latent_{t}"].grad.cpu() for t in range(len(class_names))])
+    checks = [(k[5:], named[k[5:]].grad.detach().cpu(), torch.from_numpy(g[k])) for k in g if k.startswith("grad_") and k != "grad_latents"]
+    checks.append(("latent_vector_dict (all tracks)", got_lat, torch.from_numpy(g["grad_latents"])))
+    for k, got, want in checks:
+        got, want = got.double(), want.double()
+        rel = float((got - want).norm() / want.norm())
+        cos = float((got * want).sum() / (got.norm() * want.norm()))
+        ok = rel <= 5e-3 and cos >= 0.99999
+        report.append(f"{'ok ' if ok else 'BAD'} {k}: rel {rel:.2e} cos {cos:.5f}")
+    print("\n".join(report))
+    assert not [r for r in report if r.startswith("BAD")], "\n".join(report)
+    # the proposal levels hand the object networks no gradient (models.py:447-449), the static field does get one
+    assert named["prop_mlp_0.encoder.embeddings"].grad.abs().sum() > 0
+    # and the trained parameters go back into the fused inference path (objects.DynamicModel) under the reference's names
+    from nerflidar_hip.objects import DynamicModel
+    dm = DynamicModel(mc, tm.reference_state_dict(), g["tracks"], class_names, device="cuda:0", obj_log2_hashmap=lg)
+    r, _ = dm.render_rays({k: v for k, v in batch.items() if k in ("origins", "directions", "viewdirs", "radii", "near", "far", "base_x", "base_y", "timestamp")})
+    dd = np.abs(r["depth"].cpu().numpy() - rend[-1]["depth"].detach().cpu().numpy())   # fused bf16 kernels against the torch fp32 stacks on a
+    assert np.median(dd) < 1e-3 and np.mean(dd > 1e-2) <= 0.05, (np.median(dd), dd.max())   # white-noise scene: a ray may flip its surface
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("F,M", [(6, 64 * 64 * 7 + 13), (8, 4096), (16, 100), (1, 64)])
 def test_fused_prop_density_network_matches_torch(F, M):
     """`nlr_prop_mlp_forward` / `_backward` (PropMLP density_layer, ZI/models.py:887-889) against the same two nn.Linear in torch:
