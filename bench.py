@@ -64,6 +64,8 @@ def parse_args(argv=None):
                     "`python -m nerflidar_hip.train_scene` leaves beside it)")
     ap.add_argument("--weight-scale", type=float, default=None, help="diagnostic (profiles/r04_power_trace.txt): multiply every synthetic "
                     "parameter by this factor; 0 renders all-zero weights and tables - the same instruction stream with no operand toggling")
+    ap.add_argument("--mlp-workgroups", type=int, default=0, help="diagnostic (scripts/mlp_cu_sweep.sh): cap the persistent MLP grid at n workgroups "
+                    "(nlr_debug_set; recorded in the line as `debug_switches`)")
     ap.add_argument("--inflate-log2", type=int, default=None, help="with --ckpt: re-lay the checkpoint's hash maps out at 2^N rows per hashed "
                     "level (nerflidar_hip.weights.inflate_hashmaps: the same field bit for bit, with the footprint and the access pattern "
                     "of the larger maps; 21 = the full-size configuration)")
@@ -324,6 +326,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
+    if args.mlp_workgroups:
+        _lib.check(_lib.lib().nlr_debug_set(_lib.DBG_MLP_WORKGROUPS, args.mlp_workgroups))
     tdt = torch.float16 if args.table_dtype == "f16" else torch.float32
     ckpt_note = None
     if args.ckpt:
@@ -471,7 +475,8 @@ def main():
         bsha, ssha = buildinfo.binary_sha(), buildinfo.kernel_source_sha()
         prof = os.path.join(ROOT, "profiles", PMC_PROFILE)
         plain = (world == 1 and args.workload == "C2" and not args.chunk and not emul and args.width == W_COLS and args.table_dtype == "f32"
-                 and args.precision == 2 and args.log2_hashmap is None and not args.ckpt and not args.static_origin and args.weight_scale is None)
+                 and args.precision == 2 and args.log2_hashmap is None and not args.ckpt and not args.static_origin and args.weight_scale is None
+                 and not args.mlp_workgroups)
         traffic, tnote = pmc_traffic(prof, bsha, ssha, "nlr_mlp_kernel", plain)
         # second ceiling: the gather side, priced in bytes that really cross the L2's memory-side port.  achieved = PMC counter
         # bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section; the committed profile of THIS binary) / the
@@ -541,6 +546,7 @@ def main():
                                            "2 056 TFLOP/s at 2.39 GHz on all-zero operands): profiles/r04_power_trace.txt"},
             "roofline_gather": rg,
             "roofline_prop": rp,
+            "debug_switches": {"force_generic_level_body": L.nlr_debug_get(_lib.DBG_FORCE_GENERIC), "mlp_workgroups": L.nlr_debug_get(_lib.DBG_MLP_WORKGROUPS)},
             "kernel_source_sha": bsha[:16],
             "binary_stale": buildinfo.stale(),
         }

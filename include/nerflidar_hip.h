@@ -234,6 +234,21 @@ const char *nlr_kernel_names(void);
  * (buildinfo.kernel_source_sha() != nlr_build_sha()). */
 const char *nlr_build_sha(void);
 
+/* Diagnostic switches (round 4, ADVICE r3: they used to be environment variables read inside the library).  Process-wide, explicit,
+ * and readable back so that a benchmark line can record them; both default to 0 and nothing else in the library reads the environment.
+ *   NLR_DBG_FORCE_GENERIC (key 0): 1 sends the fused encode / proposal launches through the generic level body (nlr_encode8g_kernel /
+ *     nlr_prop8g_kernel) - the bit-identity test of the fast body.
+ *   NLR_DBG_MLP_WORKGROUPS (key 1): n > 0 caps the persistent MLP grid of models created AFTERWARDS at n workgroups (power / clock
+ *     experiments, profiles/r03_mlp_cu_sweep.txt). */
+#define NLR_DBG_FORCE_GENERIC 0
+#define NLR_DBG_MLP_WORKGROUPS 1
+int nlr_debug_set(uint32_t key, int value);
+int nlr_debug_get(uint32_t key);
+/* 1 when the fused kernels' fast level body covers this grid (see csrc/nlr_level_fast.h:nlr_level_fast_ok), 0 when the generic body
+ * serves it; host arithmetic only (offsets_host [L+1]). */
+int nlr_grid_fast_path(const int32_t *offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, int table_dtype, uint32_t gridtype,
+                       int align_corners, uint32_t interp);
+
 /* Per-kernel timing with HIP events recorded on the SAME stream the kernels are launched on.
  * nlr_profile_begin arms the model: every launch made by nlr_render_rays / nlr_mlp_level is then
  * bracketed by an event pair.  nlr_profile_end synchronises the stream, writes total milliseconds and

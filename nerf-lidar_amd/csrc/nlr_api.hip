@@ -251,7 +251,9 @@ static int build_level(NlrModel *m, LevelModel &lv, const NlrMlpDesc &d, uint32_
     auto push_bias = [&](const float *b, uint32_t n, uint32_t pad) {
         for (uint32_t i = 0; i < pad; ++i) bias.push_back(i < n ? b[i] : 0.0f);
     };
-    const uint32_t Fp32 = ((lv.F + 31) / 32) * 32;
+    // the kernel instances take two 32-feature k-blocks of grid features: up to 64, fewer are zero-padded (16 levels x 2 = 32 features,
+    // the GridEncoder's own default, Z/gridencoder/grid.py:96-110, included)
+    const uint32_t Fp32 = lv.F <= 64 ? 64 : ((lv.F + 31) / 32) * 32;
     TapeBuilder trunk;
     // density trunk
     trunk.add(mat_from(d.density0, 0, lv.F), 64, Fp32, crit);
@@ -361,11 +363,10 @@ extern "C" int nlr_model_create(const NlrModelDesc *desc, NlrModel **out, void *
             NLR_FAIL(NLR_ERR_HIP, "model_create: cannot query the current device");
         }
         m->cus = (uint32_t)n;
-        // diagnostic: run the persistent MLP grid on fewer workgroups than CUs (power / clock experiments)
-        if (const char *e = getenv("NLR_MLP_WORKGROUPS")) {
-            const int w = atoi(e);
-            if (w > 0 && w < n) m->cus = (uint32_t)w;
-        }
+        // diagnostic: run the persistent MLP grid on fewer workgroups than CUs (power / clock experiments); explicit
+        // switch, not an environment variable (nlr_debug_set)
+        const int w = nlr_debug_get(NLR_DBG_MLP_WORKGROUPS);
+        if (w > 0 && w < n) m->cus = (uint32_t)w;
     }
     m->num_levels = desc->num_levels;
     m->dilation_multiplier = desc->dilation_multiplier;
@@ -501,7 +502,7 @@ static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays 
                          float *rgb, float *sem, float *inten, float *prop_feat, hipStream_t st, bool internal_feat = false,
                          float *seg = nullptr, float *dnorm = nullptr) {
     // features in the workspace (never seen by the caller) take the piece-major layout when the fast kernels apply
-    const int piece_major = (internal_feat && !lv.is_prop && lv.gp.C == 4 && n <= 8 && lv.F % 4 == 0) ? 1 : 0;
+    const int piece_major = (internal_feat && !lv.is_prop && n <= 8 && lv.F % 4 == 0) ? 1 : 0;  // any level_dim in {1, 2, 4, 8}: nlr_feat_ptr
     CastParams cp;
     int rc = nlr_fill_cast_params(&cp, rays, tdist, rand_deg, N, lv.S, n, mloops, m->std_scale);
     if (rc) return rc;

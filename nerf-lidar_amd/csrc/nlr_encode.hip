@@ -193,6 +193,19 @@ __device__ __forceinline__ float nlr_group8_sum(float v) {
     return v;
 }
 
+// Address of feature f = l * C + c of sample m.  piece_major (the fused path's internal layout, needs L * C % 4 == 0): [L*C/4][M][4] - a
+// 4-float piece is C = 4: one level, C = 2: two levels, C = 1: four levels, C = 8: half a level; the 8 samples of a wave write one
+// 128-byte run per piece and the MLP kernel's lanes (= samples) read 16 B each from consecutive addresses.  Otherwise row-major [M, L*C]
+// (public nlr_mlp_level `features`).
+template <int C>
+__device__ __forceinline__ float *nlr_feat_ptr(float *feat, int piece_major, uint32_t M, uint32_t m, uint32_t l, uint32_t L) {
+    if (piece_major) {
+        const uint32_t f = l * C;
+        return feat + ((size_t)(f >> 2) * M + m) * 4 + (f & 3u);
+    }
+    return feat + (size_t)m * L * C + l * C;
+}
+
 template <typename T, int C>
 __global__ void __launch_bounds__(256) nlr_encode8g_kernel(CastParams cp, GridParams gp, int re_weights, float *__restrict__ feat,
                                                           int piece_major) {
@@ -227,12 +240,16 @@ __global__ void __launch_bounds__(256) nlr_encode8g_kernel(CastParams cp, GridPa
 #pragma unroll
         for (int c = 0; c < C; ++c) a[c] = nlr_group8_sum(a[c]);
         if (in && j == (l & 7)) {  // spread the row stores over the lanes of the group
-            // piece_major (C == 4, the fused path's internal layout): [L][M][4] - the 8 samples of a wave write one 128-byte
-            // run per level and the MLP kernel's lanes (= samples) read 16 B each from consecutive addresses; the row-major
-            // [M, L*C] form (public nlr_mlp_level `features`) leaves both sides with 16-byte pieces at a 160-byte stride.
-            float *f = (piece_major && C == 4) ? feat + ((size_t)l * M + m) * 4 : feat + (size_t)m * gp.L * C + l * C;
+            // (layouts: nlr_feat_ptr)
+            if constexpr (C == 8) {  // two pieces per level
+                float *f0 = nlr_feat_ptr<4>(feat, piece_major, M, m, 2 * l, 2 * gp.L), *f1 = nlr_feat_ptr<4>(feat, piece_major, M, m, 2 * l + 1, 2 * gp.L);
 #pragma unroll
-            for (int c = 0; c < C; ++c) f[c] = a[c] * inv_n;
+                for (int c = 0; c < 4; ++c) f0[c] = a[c] * inv_n, f1[c] = a[4 + c] * inv_n;
+            } else {
+                float *f = nlr_feat_ptr<C>(feat, piece_major, M, m, l, gp.L);
+#pragma unroll
+                for (int c = 0; c < C; ++c) f[c] = a[c] * inv_n;
+            }
         }
     }
 }
@@ -387,7 +404,13 @@ __device__ __forceinline__ void nlr_encode8_block(const CastParams &cp, const Gr
         float a[C];
         nlr_group8_sum_to(r, a);
         if (in && j == (l & 7)) {  // spread the row stores over the lanes of the group (layouts: see nlr_encode8g_kernel)
-            float *f = (piece_major && C == 4) ? feat + ((size_t)l * M + m) * 4 : feat + (size_t)m * gp.L * C + l * C;
+            if constexpr (C == 8) {  // two pieces per level
+                float *f0 = nlr_feat_ptr<4>(feat, piece_major, M, m, 2 * l, 2 * gp.L), *f1 = nlr_feat_ptr<4>(feat, piece_major, M, m, 2 * l + 1, 2 * gp.L);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) f0[c] = a[c] * inv_n, f1[c] = a[4 + c] * inv_n;
+                continue;
+            }
+            float *f = nlr_feat_ptr<C>(feat, piece_major, M, m, l, gp.L);
             if constexpr (C == 4) {
                 // one 16-byte non-temporal store: the features are a 0.67 GB stream per sweep that the MLP kernel reads once; kept out of
                 // the L2's recently-used set they do not evict table lines the next samples will gather again
@@ -649,12 +672,23 @@ int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist
     return NLR_OK;
 }
 
-// Test hook (tests/test_hip_parity.py::test_fast_level_body_is_bit_identical_to_the_generic_one): NLR_ENCODE_GENERIC=1 in the
-// environment sends every launch through the round-2 kernels (nlr_encode8g_kernel / nlr_prop8g_kernel), which otherwise serve only the
-// grids outside the fast body's envelope.  Read per launch: a getenv is nothing next to a kernel launch.
-static bool nlr_force_generic() {
-    const char *e = getenv("NLR_ENCODE_GENERIC");
-    return e && e[0] == '1';
+// Diagnostic switches (include/nerflidar_hip.h: nlr_debug_set / nlr_debug_get): explicit and readable back; the library reads no
+// environment variable.  [0] force the generic level body, [1] cap of the persistent MLP grid for models created afterwards.
+#include <atomic>
+static std::atomic<int> nlr_debug_switch[2] = {{0}, {0}};
+extern "C" int nlr_debug_set(uint32_t key, int value) {
+    NLR_CHECK_ARG(key < 2, "debug_set: unknown key %u", key);
+    nlr_debug_switch[key].store(value);
+    return NLR_OK;
+}
+extern "C" int nlr_debug_get(uint32_t key) { return key < 2 ? nlr_debug_switch[key].load() : 0; }
+static bool nlr_force_generic() { return nlr_debug_switch[NLR_DBG_FORCE_GENERIC].load() != 0; }
+
+extern "C" int nlr_grid_fast_path(const int32_t *offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, int table_dtype, uint32_t gridtype,
+                                  int align_corners, uint32_t interp) {
+    GridParams gp;
+    if (!offsets_host || nlr_fill_grid_params(&gp, offsets_host, table_dtype, offsets_host, L, C, S, H, gridtype, align_corners, interp)) return 0;
+    return nlr_level_fast_ok(gp) ? 1 : 0;
 }
 
 #ifdef NLR_DBG_ENV

@@ -159,16 +159,21 @@ struct NlrPair<__half, 4> {
     }
 };
 
-// Can the fast body run this grid?  (host)
+// Can the fast body run this grid?  (host)  What its 32-bit arithmetic needs, and nothing more (round 3's limits were written for a
+// 24-bit multiply the body no longer uses: they sent e.g. every grid finer than 2^14 to the generic kernels):
+//   * every level dense (mode 0) or hashed with a power-of-two table (mode 1); linear interpolation, align_corners = False;
+//   * byte offsets inside the whole table fit 32 bits (the gathers are `global_load ... v_off, s[base:base+1]` with a 32-bit v_off relative
+//     to the LEVEL's base, and the level base itself is added on the scalar unit in 64 bits: the bound is per level);
+//   * hashed levels: the kept bits of the wrapped products are the low log2(hsize) + E (E = log2 of the entry's bytes) - multiplication
+//     and addition mod 2^32 preserve them exactly when log2(hsize) + E <= 32, which the byte bound above already implies;
+//   * dense levels: x + y * step + z * step^2 < hsize (mode 0 by construction), times the entry size below 2^32: the same bound.
 static inline bool nlr_level_fast_ok(const GridParams &gp) {
     if (gp.interp != 0 || gp.align_corners != 0) return false;
     const uint64_t entry = (uint64_t)gp.C * (gp.table_dtype == 0 ? 4 : 2);
     for (uint32_t l = 0; l < gp.L; ++l) {
         if (gp.mode[l] > 1) return false;
-        if (gp.mode[l] == 1 && gp.hsize[l] > (1u << 24)) return false;                        // P mod hsize must fit v_mul_u32_u24
-        if (gp.mode[l] == 0 && (uint64_t)gp.step[l] * gp.step[l] * entry >= (1u << 24)) return false;
-        if (gp.res[l] >= (1u << 14)) return false;                                             // coordinate << e must stay below 2^24
-        if (((uint64_t)gp.offset[l] + gp.hsize[l]) * entry >= (1ull << 32)) return false;      // 32-bit byte offsets
+        if ((uint64_t)gp.hsize[l] * entry > (1ull << 32)) return false;   // byte offsets relative to the level's base
+        if (gp.res[l] >= (1u << 30)) return false;                         // coordinate + 1 and its shift by E <= 5 stay exact in 32 bits mod 2^32
     }
     return true;
 }

@@ -59,7 +59,7 @@ static bool have_instance(uint32_t W, uint32_t HT, uint32_t prec, uint32_t comp)
 bool nlr_mlp_can_composite(uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, uint32_t F, uint32_t S, uint32_t K, bool use_int, uint64_t M) {
     const uint32_t per = (S + 63) / 64;
     return WB == 256 && have_instance(W, HT, prec, 1) && S % 32 == 0 && per > 0 && 32 % per == 0 && K + (use_int ? 1u : 0u) <= 29 &&
-           F % 4 == 0 && F > 32 && F <= 4 * NLR_STAGE_PIECES && M >= 32;
+           F % 4 == 0 && F >= 4 && F <= 4 * NLR_STAGE_PIECES && M >= 32;
 }
 
 int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uint32_t prec, uint32_t cus, hipStream_t st) {
@@ -75,7 +75,7 @@ int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uin
     // persistent workgroups: one per CU (~156 KiB of LDS each, so one is all a CU holds), tiles of 256 samples round-robin
     const uint32_t ntiles = (P.M + NLR_TILE - 1) / NLR_TILE;
     dim3 grid(ntiles < cus ? ntiles : cus);
-    if (WB == 256 && FT == 2 && P.F % 4 == 0) {
+    if (WB == 256 && FT <= 2 && P.F % 4 == 0) {  // (instances are built for two k-blocks; a tape of F <= 32 features is padded to two)
 #define NLR_TRY(wt, ht, pr, cm)                                   \
     if (W == wt * 32 && HT == ht && prec == pr && comp == cm) {   \
         NLR_MLP_LAUNCH_NAME(wt, ht, pr, cm)(P, grid, st);         \
@@ -87,6 +87,6 @@ int nlr_launch_mlp(const MlpParams &P, uint32_t W, uint32_t WB, uint32_t HT, uin
     }
     NLR_FAIL(NLR_ERR_UNSUPPORTED,
              "NerfMLP shape (width %u, bottleneck %u, %u grid features, %u head tiles, precision %u) has no fused kernel "
-             "instance; built: view widths 128 and 256 with 0, 1 or 2 heads (semantic / intensity), bottleneck 256, 33..64 grid features",
+             "instance; built: view widths 128 and 256 with 0, 1 or 2 heads (semantic / intensity), bottleneck 256, 4..64 grid features (multiple of 4)",
              W, WB, P.F, HT, prec);
 }

@@ -78,7 +78,7 @@ class NlrOut(C.Structure):
 
 _lib = None
 
-EXPORTS = ["nlr_last_error", "nlr_version", "nlr_build_sha", "nlr_grid_encode_forward", "nlr_grid_encode_backward", "nlr_grad_total_variation", "nlr_level_scale",
+EXPORTS = ["nlr_last_error", "nlr_version", "nlr_build_sha", "nlr_debug_set", "nlr_debug_get", "nlr_grid_fast_path", "nlr_grid_encode_forward", "nlr_grid_encode_backward", "nlr_grad_total_variation", "nlr_level_scale",
            "nlr_sample_u", "nlr_model_create", "nlr_model_destroy", "nlr_model_set_table", "nlr_workspace_bytes",
            "nlr_render_rays", "nlr_kernel_names", "nlr_resample_level", "nlr_mlp_level", "nlr_composite_level",
            "nlr_profile_begin", "nlr_profile_begin_kinds", "nlr_profile_end", "nlr_range_workspace_bytes", "nlr_range_project",
@@ -89,6 +89,7 @@ EXPORTS = ["nlr_last_error", "nlr_version", "nlr_build_sha", "nlr_grid_encode_fo
            "nlr_train_plan_create", "nlr_train_plan_destroy", "nlr_train_act_width", "nlr_train_param_layout", "nlr_train_pack",
            "nlr_mlp_train_forward", "nlr_mlp_train_backward"]
 NLR_K_COUNT = 6
+DBG_FORCE_GENERIC, DBG_MLP_WORKGROUPS = 0, 1
 
 
 def lib():
@@ -121,6 +122,9 @@ def lib():
         L.nlr_grid_encode_backward_ws.argtypes = L.nlr_grid_encode_backward.argtypes[:-1] + [c_fp, C.c_size_t, c_fp]
         L.nlr_grid_backward_workspace_bytes.restype = C.c_size_t
         L.nlr_grid_backward_workspace_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, c_fp, C.c_uint32, C.c_int]
+        L.nlr_debug_set.argtypes = [C.c_uint32, C.c_int]
+        L.nlr_debug_get.argtypes = [C.c_uint32]
+        L.nlr_grid_fast_path.argtypes = [c_fp, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint32]
         L.nlr_grad_total_variation.argtypes = [c_fp, c_fp, c_fp, c_fp, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
                                                C.c_uint32, C.c_uint32, C.c_int, c_fp]
         L.nlr_render_rays.argtypes = [c_fp, C.POINTER(NlrRays), C.c_uint32, C.POINTER(NlrRenderCfg), C.POINTER(NlrOut),

@@ -162,6 +162,10 @@ def workload(name: str, log2_hashmap: Optional[int] = None) -> ModelConfig:
     elif name == "P_W128I":  # width 128 with both heads
         mc = ModelConfig(num_prop_samples=(), num_nerf_samples=64, num_levels=1, config=Config(use_intensity=True),
                          nerf_mlp=MLPConfig(net_depth_viewdirs=4, net_width_viewdirs=128))
+    elif name == "P_F32":  # the GridEncoder's own default grid (16 levels x 2 features = 32, Z/gridencoder/grid.py:96-110) under the NerfMLP
+        mc = ModelConfig(nerf_mlp=MLPConfig(grid_level_dim=2, grid_disired_resolution=16 * 2 ** 15))
+    elif name == "P_F20":  # NerfMLP.grid_level_dim = 2 alone: 10 levels x 2 = 20 features
+        mc = ModelConfig(config=Config(use_intensity=True), nerf_mlp=MLPConfig(grid_level_dim=2))
     elif name == "P_D3":  # odd view depths: 3 x 256 ...
         mc = ModelConfig(nerf_mlp=MLPConfig(net_depth_viewdirs=3, net_width_viewdirs=256))
     elif name == "P_D5":  # ... and 5 x 128

@@ -268,6 +268,8 @@ def gen_mlp_and_forward():
         ("P_W128I", "P_W128I", 15, 64, 16, 5, True),
         ("P_D3", "P_D3", 15, 64, 16, 6, True),
         ("P_D5", "P_D5", 15, 64, 16, 7, True),
+        ("P_F32", "P_F32", 15, 64, 16, 8, True),
+        ("P_F20", "P_F20", 15, 64, 16, 9, True),
     ]
     only = os.environ.get("NLR_GOLDEN_ONLY")  # regenerate a subset: comma-separated case names
     if only:

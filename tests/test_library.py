@@ -228,3 +228,33 @@ def test_binary_carries_its_source_hash_and_stale_builds_lose_traffic(tmp_path, 
     json.dump({"kernel_source_sha": "0" * 64, "kernels": {}}, open(prof, "w"))
     t, note = bench.pmc_traffic(str(prof), b, b, "nlr_mlp_kernel")
     assert t is None and "was measured on kernel source 000000000000" in note
+
+
+def test_fast_level_body_envelope_is_what_32_bit_arithmetic_needs():
+    """`nlr_level_fast_ok` just inside / outside each of its limits (host arithmetic only, no table is touched).  A level of
+    2^28 sixteen-byte entries is 4 GiB = 2^32 bytes: the last size whose byte offsets fit; 2^29 is out.  Smoothstep, align_corners and
+    the tiled grid type (non power-of-two wrap) are out; resolutions far beyond round 3's 2^14 limit are in."""
+    import numpy as np
+    from nerflidar_hip import _lib
+    L_ = _lib.lib()
+
+    def fast(offsets, Lv, C, dtype=0, gridtype=0, align=0, interp=0, S=1.0, H=16):
+        off = np.ascontiguousarray(offsets, np.int32)
+        return L_.nlr_grid_fast_path(off.ctypes.data, Lv, C, float(S), H, dtype, gridtype, align, interp)
+
+    def table(Lv, log2, H=16):
+        sizes = [min(2 ** log2, (H * 2 ** l + 1) ** 3) for l in range(Lv)]
+        sizes = [-(-s_ // 8) * 8 for s_ in sizes]
+        return np.concatenate([[0], np.cumsum(sizes)])
+
+    assert fast(table(10, 21), 10, 4) == 1                    # the NerfMLP grid
+    assert fast(table(16, 19), 16, 2) == 1                    # 16 levels to resolution 524 288 (round 3: generic)
+    assert fast(table(10, 21), 10, 4, interp=1) == 0          # smoothstep
+    assert fast(table(10, 21), 10, 4, align=1) == 0
+    assert fast(table(10, 21), 10, 4, gridtype=1) == 0        # tiled: wrap by modulo of a non power of two
+    # byte offsets: int32 offsets cap a whole table at 2^31 entries, so the bound is met through the entry size: 2^28 entries x 16 B in,
+    # 2^28 x 32 B (C = 8, fp32) out
+    big = np.array([0, 2 ** 28], np.int64)
+    assert fast(big, 1, 4, H=2 ** 12) == 1
+    assert fast(big, 1, 8, H=2 ** 12) == 0
+    assert fast(big, 1, 8, dtype=1, H=2 ** 12) == 1           # fp16: 16-byte entries again
