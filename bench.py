@@ -479,7 +479,7 @@ def main():
                  and not args.mlp_workgroups)
         traffic, tnote = pmc_traffic(prof, bsha, ssha, "nlr_mlp_kernel", plain)
         # second ceiling: the gather side, priced in bytes that really cross the L2's memory-side port.  achieved = PMC counter
-        # bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section; the committed profile of THIS binary) / the
+        # bytes per launch (FETCH_SIZE [x 1 for these random-line kernels, see scripts/pmc_traffic.sh] + WRITE_SIZE; the committed profile of THIS binary) / the
         # kernel's launch duration measured here with HIP events; peak = 8 TB/s HBM (the guide's measured random-gather rates from tables
         # in the Infinity Cache are 7.4-8.6 TB/s, streamed HBM 6.0-6.3 TB/s).  The algorithmic gather bytes (samples x 7 multisamples x L
         # levels x 8 corners x C channels x 4 B) are kept as a note: most of them are served by the scalar cache, by lanes sharing a
@@ -497,9 +497,12 @@ def main():
                     "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": tr, "traffic_note": note,
                     "launch_ms": round(kern[key], 4), "launches_per_step": launches_per_step,
                     "algorithmic_gather_bytes": alg_bytes, "algorithmic_gather_GBps": (alg_bytes / t_s / 1e9) if t_s > 0 else None,
-                    "note": "achieved = PMC bytes past L2 per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, Infinity-Cache hits "
-                            "included: the counter sits on the L2's fabric side) / HIP-event launch duration, against 8 TB/s; the guide's "
-                            "random-gather ceilings are 7.4-8.6 TB/s (tables in the Infinity Cache) and ~6 TB/s (HBM stream).  "
+                    "note": "achieved = PMC bytes past L2 per launch (FETCH_SIZE as tallied: for random 64-byte lines it equals the line bytes, "
+                            "calibrated with scripts/micro/gather_rand.hip, profiles/r04_fetch_size_calibration.txt - the x2 gfx950 correction "
+                            "applies to wide coalesced streams only - + WRITE_SIZE; Infinity-Cache hits included: the counter sits on the L2's "
+                            "fabric side) / HIP-event launch duration, against 8 TB/s.  The guide's gather ceilings are 7.4-8.6 TB/s for "
+                            "1 152-byte rows; for random 64-byte LINES this chip delivers 3.5-4.2 TB/s (55-66 G lines/s, "
+                            "profiles/r04_gather_rand_microbench.txt).  "
                             "algorithmic_gather_* counts every corner read of every multisample and is NOT a roofline figure (scalar-cache "
                             "path, shared look-ups, L1/L2 hits)"}
 

@@ -82,7 +82,8 @@ struct NlrEntry<__half, 4> {
     static constexpr int E = 3;
     static __device__ __forceinline__ void ld(const char *base, uint32_t off, float (&v)[4]) {
         const uint2 t = *(const uint2 *)(base + off);
-        const __half2 a = __builtin_bit_cast(__half2, t.x), b = __builtin_bit_cast(__half2, t.y);
+        const uint32_t tx = t.x, ty = t.y;  // (named scalars: see NlrPair<__half, 2>)
+        const __half2 a = __builtin_bit_cast(__half2, tx), b = __builtin_bit_cast(__half2, ty);
         v[0] = __low2float(a), v[1] = __high2float(a), v[2] = __low2float(b), v[3] = __high2float(b);
     }
 };
@@ -141,7 +142,10 @@ struct NlrPair<__half, 2> {
     static constexpr bool ok = true;
     static __device__ __forceinline__ void ld(const char *base, uint32_t off, float (&a)[2], float (&b)[2]) {
         const nlr_uint2_a4 t = *(const nlr_uint2_a4 *)(base + off);
-        const __half2 p = __builtin_bit_cast(__half2, t.x), q = __builtin_bit_cast(__half2, t.y);
+        // (through named scalars: hipcc 7.2 folds `__builtin_bit_cast(__half2, t.y)` on an ext-vector ELEMENT to element 0 - the second
+        // entry read as the first; found by the fp16 16 x 2 grid, the first grid with a dense level of 4-byte entry pairs)
+        const uint32_t tx = t.x, ty = t.y;
+        const __half2 p = __builtin_bit_cast(__half2, tx), q = __builtin_bit_cast(__half2, ty);
         a[0] = __low2float(p), a[1] = __high2float(p), b[0] = __low2float(q), b[1] = __high2float(q);
     }
 };
