@@ -352,9 +352,20 @@ __device__ __forceinline__ uint32_t nlr_xcd_block(uint32_t b, uint32_t nblocks, 
 // (the array itself is defined in nlr_level_fast.h, which reads [3])
 #define NLR_DBG_LO nlr_dbg[0]
 #define NLR_DBG_HI nlr_dbg[1]
+// experiment: processing order in 2-D tiles of the sweep ([2] = azimuth columns W, [5] x [6] = beams x columns per tile): the po-th ray
+// processed is ray beam * W + az of the tile walk
+__device__ __forceinline__ uint32_t nlr_dbg_ray(uint32_t po) {
+    const uint32_t W = (uint32_t)nlr_dbg[2], tb = (uint32_t)nlr_dbg[5], ta = (uint32_t)nlr_dbg[6];
+    if (!W || !tb || !ta) return po;
+    const uint32_t per = tb * ta, tile = po / per, within = po - tile * per, tiles_row = W / ta;
+    const uint32_t trow = tile / tiles_row, tcol = tile - trow * tiles_row;
+    return (trow * tb + within / ta) * W + tcol * ta + within % ta;
+}
+#define NLR_DBG_RAY(r) nlr_dbg_ray(r)
 #else
 #define NLR_DBG_LO 0
 #define NLR_DBG_HI 99
+#define NLR_DBG_RAY(r) (r)
 #endif
 
 struct RayRegs {
@@ -385,7 +396,8 @@ __device__ __forceinline__ void nlr_encode8_block(const CastParams &cp, const Gr
     const bool in = m < M;
     if (!in) m = M - 1;
     const bool active = in && j < cp.n;
-    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    const uint32_t pray = m / cp.S, k = m - pray * cp.S, ray = NLR_DBG_RAY(pray);
+    m = ray * cp.S + k;
     const RayRegs rr = nlr_load_ray(cp, ray, k);
     const Gauss g = nlr_cast_one(cp, ray, k, active ? j : 0, rr.t0, rr.t1, rr.o, rr.d, rr.bx, rr.by, rr.radius);
     // gridencoder.cu:124-135: a point outside [0,1]^3 encodes as zeros on every level
@@ -451,7 +463,8 @@ __global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParam
     const bool in = m < M;
     if (!in) m = M - 1;
     const bool active = in && j < cp.n;
-    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
+    const uint32_t pray = m / cp.S, k = m - pray * cp.S, ray = NLR_DBG_RAY(pray);
+    m = ray * cp.S + k;
     const RayRegs rr = nlr_load_ray(cp, ray, k);
     const Gauss g = nlr_cast_one(cp, ray, k, active ? j : 0, rr.t0, rr.t1, rr.o, rr.d, rr.bx, rr.by, rr.radius);
     const bool valid = active && !((g.x0 < 0 || g.x0 > 1) || (g.x1 < 0 || g.x1 > 1) || (g.x2 < 0 || g.x2 > 1));
@@ -698,6 +711,9 @@ static void nlr_dbg_upload(hipStream_t st) {
     if (const char *e = getenv("NLR_ENC_HI")) v[1] = atoi(e);
     if (const char *e = getenv("NLR_ENC_NOSCALAR")) v[3] = atoi(e);
     if (const char *e = getenv("NLR_ENC_NT")) v[4] = (int)strtol(e, nullptr, 0);
+    if (const char *e = getenv("NLR_ENC_SWEEPW")) v[2] = atoi(e);
+    if (const char *e = getenv("NLR_ENC_TILEB")) v[5] = atoi(e);
+    if (const char *e = getenv("NLR_ENC_TILEA")) v[6] = atoi(e);
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(nlr_dbg), v, sizeof(v), 0, hipMemcpyHostToDevice, st);
 }
 #endif

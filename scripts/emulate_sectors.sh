@@ -3,7 +3,7 @@
 # does), eager without them, and replayed from a HIP graph (bench.py --graph).  For profiles/rNN_emulated_sector_steps.txt.
 one() {
   timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | \
-    python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), 'ms/step', {k: round(v,4) for k,v in d['kernel_ms'].items()})"
+    python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), 'ms/step', {k: round(v,4) for k,v in (d['kernel_ms'] or {}).items()})"
 }
 for P in 1 2 4 8; do
   E=""; [ $P -gt 1 ] && E="--emulate-world $P"
