@@ -107,20 +107,28 @@ def analytic_drop_truth(batch: Dict[str, torch.Tensor], origin_m: torch.Tensor, 
     return mask, lr * mask
 
 
-def raydrop_batch(model: Model, sweep_ids, scale_factor: float = 1.0 / 250.0, seed: int = 0, width: int = 1024, var: bool = True):
+def raydrop_batch(model: Model, sweep_ids, scale_factor: float = 1.0 / 250.0, seed: int = 0, width: int = 1024, var: bool = True,
+                  batches=None, truth=None):
     """BASELINE config 5's input, end to end on the device: render the sweeps, project, stack -> img [B, F, 32, width], gt_mask [B, 32, width],
-    gt_range [B, 32, width] for `raydrop.train_step` (B = len(sweep_ids)), plus the per-sweep projections for `raydrop.apply_ray_drop`."""
+    gt_range [B, 32, width] for `raydrop.train_step` (B = len(sweep_ids)), plus the per-sweep projections for `raydrop.apply_ray_drop`.
+    batches: the sweeps' ray batches already on the device (a replay keeps them there); truth: (gt_mask, gt_range) from an earlier call -
+    the recorded frames do not change between epochs, only the rendering does."""
     dev = model.device
     rot = torch.from_numpy(nlidar.seeded_rotation(seed)).float().to(dev)
+    if batches is None:
+        batches = [{k: torch.from_numpy(v).to(dev) for k, v in nlidar.synthetic_sweep(width=width, seed=seed, scale_factor=scale_factor, sweep_idx=idx).items()}
+                   for idx in sweep_ids]
     imgs, masks, ranges, projs = [], [], [], []
-    for idx in sweep_ids:
-        b = {k: torch.from_numpy(v).to(dev) for k, v in nlidar.synthetic_sweep(width=width, seed=seed, scale_factor=scale_factor, sweep_idx=idx).items()}
+    for idx, b in zip(sweep_ids, batches):
         origin_m = b["origins"][0] / scale_factor
         res = render_sweep_device(model, b, scale_factor)
         img, proj = sweep_unet_input(res, origin_m, rot, var=var, width=width)
-        m, r = analytic_drop_truth(b, origin_m, rot, scale_factor, seed, idx, width)
-        imgs.append(img[0]); masks.append(m); ranges.append(r); projs.append(proj)
-    return torch.stack(imgs), torch.stack(masks), torch.stack(ranges), projs
+        imgs.append(img[0]); projs.append(proj)
+        if truth is None:
+            m, r = analytic_drop_truth(b, origin_m, rot, scale_factor, seed, idx, width)
+            masks.append(m); ranges.append(r)
+    gt_mask, gt_range = (torch.stack(masks), torch.stack(ranges)) if truth is None else truth
+    return torch.stack(imgs), gt_mask, gt_range, projs
 
 
 def main(argv=None) -> int:
