@@ -673,6 +673,20 @@ def gen_losses():
     save("fn_losses", **out)
 
 
+def gen_lr_schedule():
+    """The reference's learning-rate function (internal/math.py:54-85, the defaults of configs.py:85-88 and a short schedule) at a few
+    steps, for `training.learning_rate_decay`."""
+    print("learning-rate schedule fixture")
+    steps = np.array([0, 1, 10, 100, 1000, 2500, 5000, 12500, 24999, 25000, 30000])
+    out = dict(steps=steps)
+    for tag, kw in (("default", dict(lr_init=0.01, lr_final=0.001, max_steps=25000, lr_delay_steps=5000, lr_delay_mult=1e-8)),
+                    ("short", dict(lr_init=0.02, lr_final=0.0005, max_steps=3000, lr_delay_steps=600, lr_delay_mult=0.01)),
+                    ("nodelay", dict(lr_init=0.01, lr_final=0.001, max_steps=25000, lr_delay_steps=0, lr_delay_mult=1.0))):
+        out[tag] = np.array([rmath.learning_rate_decay(int(s_), **kw) for s_ in steps], np.float64)
+        out[tag + "_kw"] = np.array([kw["lr_init"], kw["lr_final"], kw["max_steps"], kw["lr_delay_steps"], kw["lr_delay_mult"]], np.float64)
+    save("fn_lr_schedule", **out)
+
+
 def gen_trained():
     """a TRAINED, well-conditioned scene through the reference.  `tests/golden/ckpt_trained/checkpoint_<step>.ckpt`
     was written on the GPU box by `python -m nerflidar_hip.train_scene` (`training.training_step` on the analytic scene of
@@ -957,6 +971,9 @@ if __name__ == "__main__":
     if os.environ.get("NLR_GOLDEN_ONLY") == "train_step":
         gen_train_step()
         raise SystemExit(0)
+    if os.environ.get("NLR_GOLDEN_ONLY") == "lr":
+        gen_lr_schedule()
+        raise SystemExit(0)
     if os.environ.get("NLR_GOLDEN_ONLY") == "trained":
         gen_trained()
         raise SystemExit(0)
@@ -981,5 +998,6 @@ if __name__ == "__main__":
     gen_losses()
     gen_train_step()
     gen_train_step_obj()
+    gen_lr_schedule()
     gen_trained()
     print("done")
