@@ -235,13 +235,15 @@ const char *nlr_kernel_names(void);
 const char *nlr_build_sha(void);
 
 /* Diagnostic switches (round 4, ADVICE r3: they used to be environment variables read inside the library).  Process-wide, explicit,
- * and readable back so that a benchmark line can record them; both default to 0 and nothing else in the library reads the environment.
+ * and readable back so that a benchmark line can record them; all default to 0 and nothing else in the library reads the environment.
  *   NLR_DBG_FORCE_GENERIC (key 0): 1 sends the fused encode / proposal launches through the generic level body (nlr_encode8g_kernel /
  *     nlr_prop8g_kernel) - the bit-identity test of the fast body.
  *   NLR_DBG_MLP_WORKGROUPS (key 1): n > 0 caps the persistent MLP grid of models created AFTERWARDS at n workgroups (power / clock
- *     experiments, profiles/r03_mlp_cu_sweep.txt). */
+ *     experiments, profiles/r03_mlp_cu_sweep.txt).
+ *   NLR_DBG_BINNED_C4 (key 2): 1 lets the binned scatter (nlr_grid_encode_backward_ws) take level_dim = 4 grids as well (A/B only). */
 #define NLR_DBG_FORCE_GENERIC 0
 #define NLR_DBG_MLP_WORKGROUPS 1
+#define NLR_DBG_BINNED_C4 2
 int nlr_debug_set(uint32_t key, int value);
 int nlr_debug_get(uint32_t key);
 /* 1 when the fused kernels' fast level body covers this grid (see csrc/nlr_level_fast.h:nlr_level_fast_ok), 0 when the generic body

@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(1024) nlr_grid_bwd_lds_kernel(const float *__r
 // =====================================================================================================================================
 #define NLR_BIN_FLOATS 32768u   // floats of table per bucket (128 KiB of LDS in pass 2)
 #define NLR_BIN_CHUNK 8192u     // points per pass-1 workgroup (segments of ~1 000 items per bucket: pass 2 reads them in long runs)
-#define NLR_BIN_SPLIT 16u       // pass-2 workgroups per bucket (a dense level concentrates its items in the few buckets the scene occupies)
+#define NLR_BIN_SPLIT 16u       // pass-2 workgroups per bucket at most (a dense level concentrates its items in the few buckets the scene occupies)
 #define NLR_BIN_MAXB 256u       // buckets per level at most (2^21 entries x 4 channels)
 
 struct BinArgs {
@@ -399,6 +399,7 @@ struct BinArgs {
     uint32_t level[NLR_MAX_GRID_LEVELS];
     uint32_t nb[NLR_MAX_GRID_LEVELS];   // buckets of that level
     uint32_t nchunks, shift;   // entry index >> shift = bucket
+    uint32_t split;            // pass-2 workgroups per bucket: every one flushes a whole bucket image, so fewer for the large C = 4 tables
     uint32_t *counts, *starts; // [nlev][NLR_BIN_MAXB][nchunks]
     uint32_t *item_idx;        // [nlev][nchunks][NLR_BIN_CHUNK * 8]
     float *item_val;           // [nlev][nchunks][NLR_BIN_CHUNK * 8][C]
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(1024) nlr_grid_bwd_acc_kernel(GridParams gp, f
     const int lane = threadIdx.x & 63;
     // 16 waves per workgroup: the 128 KiB image leaves room for ONE workgroup per CU, and a segment read is a dependent chain (start /
     // count, then items), so the loads in flight per CU are what the waves of this workgroup bring (4 waves: 8-10 ms per launch)
-    const uint32_t wave = split * 16 + (threadIdx.x >> 6), nwaves = NLR_BIN_SPLIT * 16;
+    const uint32_t wave = split * 16 + (threadIdx.x >> 6), nwaves = a.split * 16;
     const uint32_t *cn = a.counts + ((size_t)li * NLR_BIN_MAXB + bucket) * a.nchunks;
     const uint32_t *st = a.starts + ((size_t)li * NLR_BIN_MAXB + bucket) * a.nchunks;
     // a wave takes blocks of 8 consecutive chunks (one load brings their (start, count), then the segments one by one).  Small blocks: a
@@ -547,9 +548,10 @@ static size_t nlr_bin_plan(const GridParams &gp, uint32_t B, uint32_t C, BinArgs
     while ((NLR_BIN_FLOATS / C) >> (sh + 1)) ++sh;  // log2(entries per bucket)
     a->shift = sh;
     a->nchunks = (B + NLR_BIN_CHUNK - 1) / NLR_BIN_CHUNK;
-    // C = 4 (the NerfMLP grid: 256 buckets per level, 20-byte items) loses against the atomics - 34.1 against 28.2 ms at 14.7 M points,
-    // profiles/r04_grid_scatter_ab.txt: its per-(chunk, bucket) segments are too short for the scattered item writes to combine - and stays there
-    if (C > 2) return 0;
+    // C = 4 (the NerfMLP grid: 256 buckets per level, 20-byte items): the first version lost against the atomics (34.1 against 28.2 ms at
+    // 14.7 M points, profiles/r04_grid_scatter_ab.txt); behind nlr_debug_set(2, 1) until an A/B on the final pass 2 says otherwise
+    if (C > 2 && !nlr_debug_get(2)) return 0;
+    a->split = C > 2 ? 4u : NLR_BIN_SPLIT;
     for (uint32_t l = 0; l < gp.L; ++l) {
         if (nlr_level_fits_lds(gp, l, C)) continue;
         const uint32_t nb = (gp.hsize[l] + (1u << sh) - 1) >> sh;
@@ -653,7 +655,7 @@ static int nlr_grid_backward_impl(const float *grad, const float *inputs, const 
         ba.item_val = (float *)(ba.item_idx + items);
         uint32_t nbmax = 0;
         for (uint32_t i = 0; i < ba.nlev; ++i) nbmax = ba.nb[i] > nbmax ? ba.nb[i] : nbmax;
-        dim3 g1(ba.nchunks, ba.nlev), g2b(nbmax, ba.nlev, NLR_BIN_SPLIT), b1024(1024);
+        dim3 g1(ba.nchunks, ba.nlev), g2b(nbmax, ba.nlev, ba.split), b1024(1024);
         const size_t lds = NLR_BIN_FLOATS * sizeof(float);
 #define NLR_BIN_LAUNCH(CC)                                                                                                            \
     do {                                                                                                                              \

@@ -58,4 +58,6 @@ def run(name, C, Lv, desired, S, spread):
 
 run("proposal grid 0 (res 512)", 1, 6, 512, 64, 0.01)
 run("proposal grid 1 (res 2048)", 1, 8, 2048, 64, 0.004)
+L_.nlr_debug_set(2, 1)   # NLR_DBG_BINNED_C4: let the binned path take the C = 4 grid for this comparison
 run("NerfMLP grid (res 8192)", 4, 10, 8192, 32, 0.002)
+L_.nlr_debug_set(2, 0)
