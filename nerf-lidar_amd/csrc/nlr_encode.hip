@@ -688,13 +688,13 @@ int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist
 // Diagnostic switches (include/nerflidar_hip.h: nlr_debug_set / nlr_debug_get): explicit and readable back; the library reads no
 // environment variable.  [0] force the generic level body, [1] cap of the persistent MLP grid for models created afterwards.
 #include <atomic>
-static std::atomic<int> nlr_debug_switch[3] = {{0}, {0}, {0}};
+static std::atomic<int> nlr_debug_switch[6] = {{0}, {0}, {0}, {0}, {0}, {0}};
 extern "C" int nlr_debug_set(uint32_t key, int value) {
-    NLR_CHECK_ARG(key < 3, "debug_set: unknown key %u", key);
+    NLR_CHECK_ARG(key < 6, "debug_set: unknown key %u", key);
     nlr_debug_switch[key].store(value);
     return NLR_OK;
 }
-extern "C" int nlr_debug_get(uint32_t key) { return key < 3 ? nlr_debug_switch[key].load() : 0; }
+extern "C" int nlr_debug_get(uint32_t key) { return key < 6 ? nlr_debug_switch[key].load() : 0; }
 static bool nlr_force_generic() { return nlr_debug_switch[NLR_DBG_FORCE_GENERIC].load() != 0; }
 
 extern "C" int nlr_grid_fast_path(const int32_t *offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, int table_dtype, uint32_t gridtype,

@@ -220,11 +220,23 @@ extern "C" int nlr_grid_encode_forward(const float *inputs, const void *embeddin
 #undef NLR_DISPATCH_C
 }
 
-// Dense levels whose table fits an LDS copy are accumulated there by nlr_grid_bwd_lds_kernel (below) when the batch is large; both
-// kernels decide with this one predicate.
+// Levels that nlr_grid_bwd_lds_kernel (below) accumulates in LDS when the batch is large; every kernel and the bin plan decide with this
+// one predicate.  1: dense level whose whole table fits an LDS copy; 2: a coarse level beyond that (cells of 1/128 of the cube or larger:
+// a batch of LiDAR rays visits a few hundred to a few thousand of its entries), accumulated in a tagged LDS cache; 0: scattered.
 #define NLR_LDS_TABLE_FLOATS 36864  // 144 KiB
-__host__ __device__ __forceinline__ bool nlr_level_fits_lds(const GridParams &gp, uint32_t level, uint32_t C) {
-    return gp.mode[level] == 0 && gp.hsize[level] * C <= NLR_LDS_TABLE_FLOATS;
+#define NLR_LDS_CACHE_MAX_STEP 129u
+__host__ __device__ __forceinline__ int nlr_level_lds_kind(const GridParams &gp, uint32_t level, uint32_t C, int no_cache) {
+    if (gp.mode[level] == 0 && gp.hsize[level] * C <= NLR_LDS_TABLE_FLOATS) return 1;
+    if (!no_cache && C <= 4 && gp.mode[level] <= 1 && gp.step[level] <= NLR_LDS_CACHE_MAX_STEP) return 2;
+    return 0;
+}
+// The 8 corner indices of a cell with the level's mode resolved once (wave-uniform branch; nlr_common.h:nlr_corner_idx): the generic
+// nlr_grid_index pays a 32-bit modulo per corner, which made the LDS and bin kernels below issue-bound.
+__device__ __forceinline__ void nlr_corner_idx_any(const GridParams &gp, uint32_t level, const uint32_t (&pg)[3], uint32_t (&idx)[8]) {
+    const uint32_t mode = gp.mode[level];
+    if (mode == 0) nlr_corner_idx<0>(gp, level, pg, idx);
+    else if (mode == 1) nlr_corner_idx<1>(gp, level, pg, idx);
+    else nlr_corner_idx<2>(gp, level, pg, idx);
 }
 // One lane per (point, channel): the C channel atomics of a corner go out in ONE instruction as C adjacent lanes on C
 // consecutive floats, so a 64-lane atomic touches 64/C table entries instead of 64 - the L2 atomic path is paid per
@@ -232,7 +244,7 @@ __host__ __device__ __forceinline__ bool nlr_level_fits_lds(const GridParams &gp
 template <int C>
 __global__ void __launch_bounds__(256) nlr_grid_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ x,
                                                            GridParams gp, float *__restrict__ grad_table, uint32_t B,
-                                                           int grad_layout, int lds_levels) {
+                                                           int grad_layout, uint64_t level_list) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     // channel-major inside the wave: a wave owns P = 64 / C consecutive points, lane = ch * P + point.  Neighbouring lanes are
@@ -240,8 +252,7 @@ __global__ void __launch_bounds__(256) nlr_grid_bwd_kernel(const float *__restri
     // cell still leave in one instruction on C consecutive floats.
     constexpr uint32_t P = 64 / C;
     const uint32_t b0 = (t >> 6) * P + ((uint32_t)lane % P), ch = (uint32_t)lane / P;
-    const uint32_t level = blockIdx.y;
-    if (lds_levels && nlr_level_fits_lds(gp, level, C)) return;  // accumulated in LDS by nlr_grid_bwd_lds_kernel
+    const uint32_t level = (uint32_t)(level_list >> (4 * blockIdx.y)) & 15u;  // the levels nlr_grid_bwd_lds_kernel does not take
     const bool inb = b0 < B;
     // (no early exit per lane: the run scan reads its neighbours through DPP, inactive lanes would read as zero keys)
     const uint32_t b = inb ? b0 : B - 1;
@@ -281,69 +292,103 @@ __global__ void __launch_bounds__(256) nlr_grid_bwd_kernel(const float *__restri
     }
 }
 
-// Dense coarse levels whose whole table fits in LDS (17^3 x C <= 4, 33^3 x 1): every sample of a batch lands in the same few
-// thousand cells, and their global atomics serialise on those addresses (level 0 of the C = 4 grid cost 3.0 of the 8.6 ms of a
-// 1.8 M-point backward).  Here a workgroup accumulates its share of the points in an LDS copy of the level (ds_add_f32) and adds
-// the copy to the table once: global atomics per level = cells x workgroups instead of points x 8 corners.
+// The same scatter with BOTH x-corners of a cell edge in one instruction (round 4).  What an atomic costs on this chip
+// (scripts/micro/atomic_scope.hip, profiles/r04_atomic_microbench.txt): 21 G (instruction x distinct 64-byte line) pairs per second
+// chip-wide, whatever the table size (64 KiB or 32 MiB), the number of busy CUs (64 or 256), the scope, or the number of lanes that add
+// to DIFFERENT floats of the line (16 are as cheap as 1); lanes on the SAME float serialise at about the same price each.  So the
+// quantity to shrink is lines per instruction.  The corners (x, y, z) and (x + 1, y, z) are adjacent entries on a dense level and,
+// on a hashed level with even x, the entries `i` and `i ^ 1` (the x coordinate enters the hash with the prime 1, gridencoder.cu:66-84):
+// one line for both, three times out of four / every second point.  A wave here owns P = 32 / C points; lane = ch * 2P + xc * P + point,
+// so that the two x-corners of a point leave in one instruction and a 16-lane row still holds consecutive points of one channel
+// and one x-corner for the run aggregation.  Four atomic instructions per point and level instead of eight; same sums.
 template <int C>
-__global__ void __launch_bounds__(1024) nlr_grid_bwd_lds_kernel(const float *__restrict__ grad, const float *__restrict__ x, GridParams gp,
-                                                               float *__restrict__ grad_table, uint32_t B, int grad_layout) {
-    __shared__ float acc[NLR_LDS_TABLE_FLOATS];
-    const uint32_t level = blockIdx.y;
-    if (!nlr_level_fits_lds(gp, level, C)) return;  // (wave-uniform: the whole workgroup)
-    const uint32_t cells = gp.hsize[level] * C;
-    for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) acc[i] = 0.0f;
-    __syncthreads();
+__global__ void __launch_bounds__(256) nlr_grid_bwd_xpair_kernel(const float *__restrict__ grad, const float *__restrict__ x,
+                                                                 GridParams gp, float *__restrict__ grad_table, uint32_t B,
+                                                                 int grad_layout, uint64_t level_list, uint32_t level_mask) {
+    static_assert(C == 1 || C == 2 || C == 4, "x-pair scatter: C in {1, 2, 4}");
+    const uint32_t level = (uint32_t)(level_list >> (4 * blockIdx.y)) & 15u;
+    if (level_mask && !((level_mask >> level) & 1u)) return;  // NLR_DBG_SCATTER_LEVELS: per-level timing
+    constexpr uint32_t P = 32 / C;
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t ch = (uint32_t)lane / (2 * P), xc = ((uint32_t)lane / P) & 1u, b0 = w * P + (uint32_t)lane % P;
+    const bool inb = b0 < B;
+    const uint32_t b = inb ? b0 : B - 1;
+    const float x0 = x[(size_t)b * 3 + 0], x1 = x[(size_t)b * 3 + 1], x2 = x[(size_t)b * 3 + 2];
+    const bool valid = inb && !((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
+    if (__ballot(valid) == 0ull) return;  // wave-uniform
+    const float gc = grad_layout == 0 ? grad[((size_t)level * B + b) * C + ch] : grad[(size_t)b * gp.L * C + level * C + ch];
+    float *gt = grad_table + (size_t)gp.offset[level] * C;
     const uint32_t hsize = gp.hsize[level], res = gp.res[level];
     const float scale = gp.scale[level];
     const float half = gp.align_corners ? 0.0f : 0.5f;
-    const uint32_t total = B * C;  // one lane per (point, channel), workgroups stride over the batch
-    if constexpr (C == 1) {
-        // one channel: neighbouring lanes are neighbouring points of a ray and sit in ONE cell of these coarse levels - 64 lanes adding
-        // to one LDS word serialise.  Runs of equal entries inside a 16-lane row are merged first (nlr_run_merge), as the global
-        // scatter does; uniform control flow for the DPP scan, invalid points ride along masked.
-        const int lane = threadIdx.x & 63;
-        for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < total; t0 += gridDim.x * blockDim.x) {
-            const uint32_t t = t0 + threadIdx.x;
-            const bool inb = t < total;
-            const uint32_t b = inb ? t : total - 1;
-            const float x0 = x[(size_t)b * 3 + 0], x1 = x[(size_t)b * 3 + 1], x2 = x[(size_t)b * 3 + 2];
-            const bool valid = inb && !((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
-            const float gc = grad_layout == 0 ? grad[(size_t)level * B + b] : grad[(size_t)b * gp.L + level];
-            float pos[3] = {fmaf(valid ? x0 : 0.5f, scale, half), fmaf(valid ? x1 : 0.5f, scale, half), fmaf(valid ? x2 : 0.5f, scale, half)};
-            uint32_t pg[3];
+    float pos[3] = {fmaf(valid ? x0 : 0.5f, scale, half), fmaf(valid ? x1 : 0.5f, scale, half), fmaf(valid ? x2 : 0.5f, scale, half)};
+    uint32_t pg[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                pg[d] = (uint32_t)floorf(pos[d]);
-                pos[d] -= (float)pg[d];
-                if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
-            }
+    for (int d = 0; d < 3; ++d) {
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+        if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+    }
+    const float wx = xc ? pos[0] : 1 - pos[0];   // the weight products keep the order of the 8-corner loop: (wx * wy) * wz
+    const uint32_t px = pg[0] + xc;
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-                float ww = 1.0f;
-                uint32_t pl[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    if ((c8 >> d) & 1) {
-                        ww *= pos[d];
-                        pl[d] = pg[d] + 1;
-                    } else {
-                        ww *= 1 - pos[d];
-                        pl[d] = pg[d];
-                    }
-                }
-                const uint32_t idx = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pl[0], pl[1], pl[2]);
-                float v[1] = {ww * gc};
-                if (nlr_run_merge<1>(idx, v, valid, lane)) atomicAdd(&acc[idx], v[0]);
-            }
-        }
-    } else
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const uint32_t b = t / C, ch = t % C;
-        const float x0 = x[(size_t)b * 3 + 0], x1 = x[(size_t)b * 3 + 1], x2 = x[(size_t)b * 3 + 2];
-        if ((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1)) continue;
-        const float gc = grad_layout == 0 ? grad[((size_t)level * B + b) * C + ch] : grad[(size_t)b * gp.L * C + level * C + ch];
-        float pos[3] = {fmaf(x0, scale, half), fmaf(x1, scale, half), fmaf(x2, scale, half)};
+    for (int c4 = 0; c4 < 4; ++c4) {
+        const float wy = (c4 & 1) ? pos[1] : 1 - pos[1], wz = (c4 & 2) ? pos[2] : 1 - pos[2];
+        const uint32_t addr = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, px, pg[1] + (c4 & 1), pg[2] + (c4 >> 1)) * C + ch;
+        nlr_run_atomic<1>(gt, addr, ((1.0f * wx) * wy) * wz * gc, valid, lane);
+    }
+}
+
+// Coarse levels in LDS.  Every sample of a batch lands in the same few thousand cells of the coarse levels, and global atomics on one
+// line queue behind each other (~40 cycles each at the L2: the 33^3 level of the C = 4 grid alone kept the round-3 scatter busy for
+// 11.6 ms of a 14.7 M-point backward, profiles/r04_scatter_levels.txt).  A workgroup strides over the batch for ONE level and adds into LDS
+// (ds_add_f32), then adds its LDS image to the table once:
+//   kind 1 (direct): the level's whole table is the image (17^3 x C <= 4, 33^3 x 1);
+//   kind 2 (cache):  NS slots of C floats with a tag each; an entry claims the slot its hash names (ds_cmpst on the tag) and keeps it to
+//     the end of the workgroup; an entry that finds its slot taken by another goes to the table with a global atomic as before.  Correct
+//     for any occupancy; it pays when the batch visits fewer distinct entries than there are slots (levels up to 128^3 cells).
+// A wave is laid out channel-major as in the scatter kernels (lane = ch * P + point, P = 64 / C) and merges runs of equal addresses inside
+// a 16-lane row first (nlr_run_merge): neighbouring lanes are neighbouring points of a ray, 16 lanes adding to one LDS word serialise.
+template <int C>
+__global__ void __launch_bounds__(1024) nlr_grid_bwd_lds_kernel(const float *__restrict__ grad, const float *__restrict__ x, GridParams gp,
+                                                               float *__restrict__ grad_table, uint32_t B, int grad_layout, uint32_t direct_mask,
+                                                               uint32_t cache_mask) {
+    __shared__ float acc[NLR_LDS_TABLE_FLOATS];
+    const uint32_t level = blockIdx.y;
+    const bool direct = (direct_mask >> level) & 1u;
+    if (!direct && !((cache_mask >> level) & 1u)) return;  // (wave-uniform: the whole workgroup)
+    constexpr uint32_t NS = NLR_LDS_TABLE_FLOATS / (C + 1);  // cache: NS x C values, then NS tags
+    uint32_t *tags = (uint32_t *)(acc + NS * C);
+    const uint32_t cells = direct ? gp.hsize[level] * C : NS * C;
+    for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) acc[i] = 0.0f;
+    if (!direct)
+        for (uint32_t i = threadIdx.x; i < NS; i += blockDim.x) tags[i] = 0xffffffffu;
+    __syncthreads();
+    float *gt = grad_table + (size_t)gp.offset[level] * C;
+
+    const float scale = gp.scale[level];
+    const float half = gp.align_corners ? 0.0f : 0.5f;
+    constexpr uint32_t P = 64 / C;
+    const int lane = threadIdx.x & 63;
+    const uint32_t ch = (uint32_t)lane / P, pl0 = (uint32_t)lane % P;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), groups = (B + P - 1) / P;
+    // (uniform control flow per wave for the DPP scan: the trip count depends on the wave, invalid points ride along masked; one workgroup
+    // of 16 waves per CU: the next group's coordinates and gradient are fetched while this one is scattered)
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));  // scalar loop
+    float nx0 = 0, nx1 = 0, nx2 = 0, ngc = 0;
+    auto fetch = [&](uint32_t g) {
+        const uint32_t bb = g * P + pl0 < B ? g * P + pl0 : B - 1;
+        nx0 = x[(size_t)bb * 3 + 0], nx1 = x[(size_t)bb * 3 + 1], nx2 = x[(size_t)bb * 3 + 2];
+        ngc = grad_layout == 0 ? grad[((size_t)level * B + bb) * C + ch] : grad[(size_t)bb * gp.L * C + level * C + ch];
+    };
+    if (g0 < groups) fetch(g0);
+    for (uint32_t g = g0; g < groups; g += nwaves) {
+        const bool inb = g * P + pl0 < B;
+        const float x0 = nx0, x1 = nx1, x2 = nx2, gc = ngc;
+        if (g + nwaves < groups) fetch(g + nwaves);
+        const bool valid = inb && !((x0 < 0 || x0 > 1) || (x1 < 0 || x1 > 1) || (x2 < 0 || x2 > 1));
+        float pos[3] = {fmaf(valid ? x0 : 0.5f, scale, half), fmaf(valid ? x1 : 0.5f, scale, half), fmaf(valid ? x2 : 0.5f, scale, half)};
         uint32_t pg[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -351,28 +396,51 @@ __global__ void __launch_bounds__(1024) nlr_grid_bwd_lds_kernel(const float *__r
             pos[d] -= (float)pg[d];
             if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
         }
+        uint32_t cidx[8];
+        nlr_corner_idx_any(gp, level, pg, cidx);
+        // three sweeps over the corners so that the 8 tag exchanges of a wave are in flight together (each is an LDS round trip)
+        const NlrRuns runs = nlr_cell_runs(pg, valid, lane);
+        float vv[8];
+        bool tail[8];
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
             float ww = 1.0f;
-            uint32_t pl[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                if ((c8 >> d) & 1) {
-                    ww *= pos[d];
-                    pl[d] = pg[d] + 1;
-                } else {
-                    ww *= 1 - pos[d];
-                    pl[d] = pg[d];
-                }
+            for (int d = 0; d < 3; ++d) ww *= ((c8 >> d) & 1) ? pos[d] : 1 - pos[d];
+            vv[c8] = nlr_runs_sum(runs, ww * gc);
+            tail[c8] = runs.tail;
+        }
+        if (direct) {
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8)
+                if (tail[c8]) atomicAdd(&acc[cidx[c8] * C + ch], vv[c8]);
+        } else {
+            uint32_t slot[8], was[8];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                slot[c8] = __umulhi(cidx[c8] * 2654435761u, NS);
+                was[c8] = tail[c8] ? atomicCAS(&tags[slot[c8]], 0xffffffffu, cidx[c8]) : 0u;
             }
-            atomicAdd(&acc[nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pl[0], pl[1], pl[2]) * C + ch], ww * gc);
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8)
+                if (tail[c8]) {
+                    if (was[c8] == 0xffffffffu || was[c8] == cidx[c8]) atomicAdd(&acc[slot[c8] * C + ch], vv[c8]);
+                    else atomicAdd(gt + (size_t)cidx[c8] * C + ch, vv[c8]);
+                }
         }
     }
     __syncthreads();
-    float *gt = grad_table + (size_t)gp.offset[level] * C;
-    for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) {
-        const float v = acc[i];
-        if (v != 0.0f) atomicAdd(gt + i, v);
+    if (direct) {
+        for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) {
+            const float v = acc[i];
+            if (v != 0.0f) atomicAdd(gt + i, v);
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) {
+            const uint32_t tag = tags[i / C];
+            const float v = acc[i];
+            if (tag != 0xffffffffu && v != 0.0f) atomicAdd(gt + (size_t)tag * C + i % C, v);
+        }
     }
 }
 
@@ -413,7 +481,7 @@ __global__ void __launch_bounds__(256) nlr_grid_bwd_bin_kernel(const float *__re
     const int lane = threadIdx.x & 63;
     for (uint32_t i = threadIdx.x; i < NLR_BIN_MAXB; i += 256) cnt[i] = 0;
     __syncthreads();
-    const uint32_t hsize = gp.hsize[level], res = gp.res[level];
+
     const float scale = gp.scale[level];
     const float half = gp.align_corners ? 0.0f : 0.5f;
     const size_t region = ((size_t)li * a.nchunks + chunk) * (NLR_BIN_CHUNK * 8);
@@ -437,25 +505,19 @@ __global__ void __launch_bounds__(256) nlr_grid_bwd_bin_kernel(const float *__re
                 pos[d] -= (float)pg[d];
                 if (gp.interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
             }
+            uint32_t cidx[8];
+            nlr_corner_idx_any(gp, level, pg, cidx);
+            const NlrRuns runs = nlr_cell_runs(pg, valid, lane);
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) {
                 float ww = 1.0f;
-                uint32_t pl[3];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    if ((c8 >> d) & 1) {
-                        ww *= pos[d];
-                        pl[d] = pg[d] + 1;
-                    } else {
-                        ww *= 1 - pos[d];
-                        pl[d] = pg[d];
-                    }
-                }
-                const uint32_t idx = nlr_grid_index(gp.gridtype, gp.align_corners, hsize, res, pl[0], pl[1], pl[2]);
+                for (int d = 0; d < 3; ++d) ww *= ((c8 >> d) & 1) ? pos[d] : 1 - pos[d];
+                const uint32_t idx = cidx[c8];
                 float v[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) v[c] = ww * g[c];
-                if (nlr_run_merge<C>(idx, v, valid, lane)) {
+                for (int c = 0; c < C; ++c) v[c] = nlr_runs_sum(runs, ww * g[c]);
+                if (runs.tail) {
                     const uint32_t bucket = idx >> a.shift;
                     if (pass == 0) {
                         atomicAdd(&cnt[bucket], 1u);
@@ -553,7 +615,7 @@ static size_t nlr_bin_plan(const GridParams &gp, uint32_t B, uint32_t C, BinArgs
     if (C > 2 && !nlr_debug_get(2)) return 0;
     a->split = C > 2 ? 4u : NLR_BIN_SPLIT;
     for (uint32_t l = 0; l < gp.L; ++l) {
-        if (nlr_level_fits_lds(gp, l, C)) continue;
+        if (nlr_level_lds_kind(gp, l, C, nlr_debug_get(NLR_DBG_NO_SCATTER_CACHE))) continue;
         const uint32_t nb = (gp.hsize[l] + (1u << sh) - 1) >> sh;
         if (nb > NLR_BIN_MAXB) return 0;  // (tables beyond 2^21 x 4 floats per level: atomics)
         a->level[a->nlev] = l;
@@ -628,19 +690,30 @@ static int nlr_grid_backward_impl(const float *grad, const float *inputs, const 
     int rc = nlr_fill_grid_params(&gp, grad_embeddings, 0, offsets_host, L, C, S, H, gridtype, align_corners, interp);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(((size_t)B * C + 255) / 256), L), block(256);  // one lane per (point, channel)
-    // levels small enough for an LDS copy go through nlr_grid_bwd_lds_kernel when the batch is large enough to pay for the flush
-    bool any_lds = false;
-    for (uint32_t l = 0; l < L; ++l) any_lds = any_lds || nlr_level_fits_lds(gp, l, C);
-    const int lds_levels = (any_lds && (size_t)B * C >= (1u << 18)) ? 1 : 0;
-    if (lds_levels) {
+    dim3 block(256);
+    // coarse levels go through nlr_grid_bwd_lds_kernel when the batch is large enough to pay for the flush
+    uint32_t direct_mask = 0, cache_mask = 0;
+    if ((size_t)B * C >= (1u << 18) && C <= 4) {
+        const int no_cache = nlr_debug_get(NLR_DBG_NO_SCATTER_CACHE);
+        for (uint32_t l = 0; l < L; ++l) {
+            const int kind = nlr_level_lds_kind(gp, l, C, no_cache);
+            if (kind == 1) direct_mask |= 1u << l;
+            if (kind == 2) cache_mask |= 1u << l;
+        }
+    }
+    const uint32_t skip_mask = direct_mask | cache_mask;
+    uint64_t level_list = 0;  // 4 bits per scattered level (NLR_MAX_GRID_LEVELS <= 16)
+    uint32_t nscat = 0;
+    for (uint32_t l = 0; l < L; ++l)
+        if (!((skip_mask >> l) & 1u)) level_list |= (uint64_t)l << (4 * nscat++);
+    const bool lds_levels = (size_t)B * C >= (1u << 18) && C <= 4;  // (the bin plan leaves the coarse levels to the LDS kernel)
+    if (skip_mask) {
         const uint32_t nb = (uint32_t)std::min<size_t>(256, ((size_t)B * C + 16383) / 16384);  // >= 16 K lanes of work per workgroup, one per CU
         dim3 g2(nb, L), b2(1024);
         switch (C) {
-            case 1: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<1>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
-            case 2: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<2>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
-            case 4: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<4>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
-            default: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<8>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout); break;
+            case 1: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<1>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, direct_mask, cache_mask); break;
+            case 2: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<2>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, direct_mask, cache_mask); break;
+            default: hipLaunchKernelGGL(nlr_grid_bwd_lds_kernel<4>, g2, b2, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, direct_mask, cache_mask); break;
         }
         NLR_LAUNCH_CHECK("nlr_grid_bwd_lds_kernel");
     }
@@ -672,12 +745,21 @@ static int nlr_grid_backward_impl(const float *grad, const float *inputs, const 
         else NLR_BIN_LAUNCH(4);
 #undef NLR_BIN_LAUNCH
         NLR_LAUNCH_CHECK("nlr_grid_bwd_bin_kernel / nlr_grid_bwd_acc_kernel");
-    } else {
+    } else if (nscat) {
+        dim3 grid((unsigned)(((size_t)B * C + 255) / 256), nscat);  // one lane per (point, channel)
         switch (C) {
-            case 1: hipLaunchKernelGGL(nlr_grid_bwd_kernel<1>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
-            case 2: hipLaunchKernelGGL(nlr_grid_bwd_kernel<2>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
-            case 4: hipLaunchKernelGGL(nlr_grid_bwd_kernel<4>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
-            default: hipLaunchKernelGGL(nlr_grid_bwd_kernel<8>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, lds_levels); break;
+            case 1: hipLaunchKernelGGL(nlr_grid_bwd_kernel<1>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list); break;
+            case 2: hipLaunchKernelGGL(nlr_grid_bwd_kernel<2>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list); break;
+            case 4:
+                if (nlr_debug_get(NLR_DBG_NO_XPAIR_SCATTER)) {
+                    hipLaunchKernelGGL(nlr_grid_bwd_kernel<4>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list);
+                } else {  // 8 points per wave: twice the waves, half the atomic instructions each
+                    NLR_CHECK_ARG((uint64_t)B * 8 < (1ull << 32), "grid_encode_backward: B = %u points do not fit the 32-bit lane index of the x-pair scatter", B);
+                    hipLaunchKernelGGL(nlr_grid_bwd_xpair_kernel<4>, dim3((unsigned)(((size_t)B * 8 + 255) / 256), nscat), block, 0, st, grad, inputs, gp,
+                                       grad_embeddings, B, grad_layout, level_list, (uint32_t)nlr_debug_get(NLR_DBG_SCATTER_LEVELS));
+                }
+                break;
+            default: hipLaunchKernelGGL(nlr_grid_bwd_kernel<8>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list); break;
         }
         NLR_LAUNCH_CHECK("nlr_grid_bwd_kernel");
     }

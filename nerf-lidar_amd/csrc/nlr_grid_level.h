@@ -92,7 +92,8 @@ __device__ __forceinline__ void nlr_run_atomic(float *gt, uint32_t addr, float v
 #define NLR_RUN_STEP(D)                                          \
     if constexpr ((D) < 16) {                                      \
         const float vo = nlr_dpp_f<SHR + (D)>(v);                 \
-        const uint32_t ho = r < (D) ? 1u : nlr_dpp_u<SHR + (D)>(head); \
+        const uint32_t hs = nlr_dpp_u<SHR + (D)>(head);           \
+        const uint32_t ho = r < (D) ? 1u : hs;                    \
         if (!head) {                                               \
             v += vo;                                               \
             head = ho;                                             \
@@ -121,7 +122,8 @@ __device__ __forceinline__ bool nlr_run_merge(uint32_t key, float (&v)[C], bool 
     {                                                                  \
         float vo[C];                                                   \
         _Pragma("unroll") for (int c = 0; c < C; ++c) vo[c] = nlr_dpp_f<SHR + (D)>(v[c]); \
-        const uint32_t ho = r < (D) ? 1u : nlr_dpp_u<SHR + (D)>(head); \
+        const uint32_t hs = nlr_dpp_u<SHR + (D)>(head);                \
+        const uint32_t ho = r < (D) ? 1u : hs;                         \
         if (!head) {                                                   \
             _Pragma("unroll") for (int c = 0; c < C; ++c) v[c] += vo[c]; \
             head = ho;                                                 \
@@ -133,4 +135,57 @@ __device__ __forceinline__ bool nlr_run_merge(uint32_t key, float (&v)[C], bool 
     NLR_MERGE_STEP(8)
 #undef NLR_MERGE_STEP
     return valid && tail;
+}
+
+// The same scan with the run structure taken from the CELL instead of the address, once for all 8 corners of a point: lanes whose points
+// sit in one cell send every corner to one entry, so the head / tail flags and the per-step "add the lane D to the left" masks of
+// nlr_run_merge are the same for the 8 corners.  nlr_cell_runs computes them from the integer cell coordinates (exact: equal cells have
+// equal corner addresses on every level type; two different cells that collide in a hashed table are simply not merged); nlr_runs_sum
+// then costs one DPP add and one select per step and corner.  Same summation tree as nlr_run_merge.
+struct NlrRuns {
+    bool m1, m2, m4, m8, tail;
+};
+template <int CTRL>
+__device__ __forceinline__ uint32_t nlr_dpp_u0(uint32_t v) {  // out-of-row source: 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float nlr_dpp_f0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ NlrRuns nlr_cell_runs(const uint32_t (&pg)[3], bool valid, int lane) {
+    constexpr int SHR = 0x110, SHL = 0x100;
+    const int r = lane & 15;
+    // invalid lanes never match a neighbour: their first coordinate is replaced by a value no cell has
+    const uint32_t k0 = valid ? pg[0] : 0xffffffffu - (uint32_t)lane;
+    // (every DPP read is issued unconditionally and lands in a temporary first: inside `&&` / `?:` the compiler may branch around it,
+    // and a DPP executed under a partial exec mask reads zeros from the lanes that are switched off)
+    const uint32_t l0 = nlr_dpp_u0<SHR + 1>(k0), l1 = nlr_dpp_u0<SHR + 1>(pg[1]), l2 = nlr_dpp_u0<SHR + 1>(pg[2]);
+    const bool same = (l0 == k0) & (l1 == pg[1]) & (l2 == pg[2]);
+    uint32_t head = ((r < 1) | !same) ? 1u : 0u;
+    NlrRuns p;
+    const uint32_t right_head = nlr_dpp_u0<SHL + 1>(head);
+    p.tail = valid & ((r >= 15) | (right_head != 0u));
+#define NLR_PLAN_STEP(D, M)                                             \
+    {                                                                   \
+        const uint32_t hs = nlr_dpp_u0<SHR + (D)>(head);                \
+        const uint32_t ho = r < (D) ? 1u : hs;                          \
+        p.M = !head;                                                    \
+        head = head ? head : ho;                                        \
+    }
+    NLR_PLAN_STEP(1, m1)
+    NLR_PLAN_STEP(2, m2)
+    NLR_PLAN_STEP(4, m4)
+    NLR_PLAN_STEP(8, m8)
+#undef NLR_PLAN_STEP
+    return p;
+}
+__device__ __forceinline__ float nlr_runs_sum(const NlrRuns &p, float v) {
+    constexpr int SHR = 0x110;
+    float t;
+    t = v + nlr_dpp_f0<SHR + 1>(v); v = p.m1 ? t : v;
+    t = v + nlr_dpp_f0<SHR + 2>(v); v = p.m2 ? t : v;
+    t = v + nlr_dpp_f0<SHR + 4>(v); v = p.m4 ? t : v;
+    t = v + nlr_dpp_f0<SHR + 8>(v); v = p.m8 ? t : v;
+    return v;
 }

@@ -89,7 +89,7 @@ EXPORTS = ["nlr_last_error", "nlr_version", "nlr_build_sha", "nlr_debug_set", "n
            "nlr_train_plan_create", "nlr_train_plan_destroy", "nlr_train_act_width", "nlr_train_param_layout", "nlr_train_pack",
            "nlr_mlp_train_forward", "nlr_mlp_train_backward"]
 NLR_K_COUNT = 6
-DBG_FORCE_GENERIC, DBG_MLP_WORKGROUPS = 0, 1
+DBG_FORCE_GENERIC, DBG_MLP_WORKGROUPS, DBG_BINNED_C4, DBG_NO_XPAIR_SCATTER, DBG_SCATTER_LEVELS, DBG_NO_SCATTER_CACHE = 0, 1, 2, 3, 4, 5
 
 
 def lib():

@@ -61,3 +61,31 @@ run("proposal grid 1 (res 2048)", 1, 8, 2048, 64, 0.004)
 L_.nlr_debug_set(2, 1)   # NLR_DBG_BINNED_C4: let the binned path take the C = 4 grid for this comparison
 run("NerfMLP grid (res 8192)", 4, 10, 8192, 32, 0.002)
 L_.nlr_debug_set(2, 0)
+
+
+def run_xpair(name, C, Lv, desired, S, spread):
+    """The C = 4 atomic scatter: one corner per instruction (rounds 2-3) against both x-corners per instruction (nlr_grid_bwd_xpair_kernel)."""
+    import math
+    x = points(S, spread)
+    B = x.shape[0]
+    offsets, sizes, pls = nw.level_table(Lv, 16, 21, desired_resolution=desired)
+    off = torch.from_numpy(np.ascontiguousarray(offsets, np.int32))
+    g = torch.randn(B, Lv * C, device=dev)
+    out = {}
+    for tag, key in (("one corner", 1), ("x-pair", 0)):
+        L_.nlr_debug_set(_lib.DBG_NO_XPAIR_SCATTER, key)
+        gt = torch.zeros(int(offsets[-1]), C, device=dev)
+        def call():
+            _lib.check(L_.nlr_grid_encode_backward(_lib.ptr(g), _lib.ptr(x), _lib.ptr(off), _lib.ptr(gt), B, 3, C, Lv, float(math.log2(pls)), 16, None, None, 0, 0, 0, 1, None))
+        call(); torch.cuda.synchronize()
+        out[tag] = gt.clone()
+        t0 = time.perf_counter()
+        for _ in range(5): call()
+        torch.cuda.synchronize()
+        out[tag + "_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+    L_.nlr_debug_set(_lib.DBG_NO_XPAIR_SCATTER, 0)
+    err = (out["one corner"] - out["x-pair"]).abs().max().item() / max(out["one corner"].abs().max().item(), 1e-9)
+    print(f"{name}: {B/1e6:.1f} M points, C={C}, L={Lv}: one corner per atomic instruction {out['one corner_ms']:.2f} ms, both x-corners {out['x-pair_ms']:.2f} ms, "
+          f"max |difference| / max |gradient| {err:.1e}")
+
+run_xpair("NerfMLP grid (res 8192), 65 536 rays x 32 samples", 4, 10, 8192, 32, 0.002)

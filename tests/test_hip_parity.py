@@ -192,12 +192,16 @@ def test_grid_backward_binned_scatter_against_oracle(C, layout):
     assert np.abs(got["binned"] - got["atomics"]).max() <= 1e-3 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("C,order", [(1, "ray"), (4, "ray"), (4, "random"), (2, "random")])
-def test_grid_backward_lds_path_against_oracle(C, order):
+@pytest.mark.parametrize("C,order,log2", [(1, "ray", 14), (4, "ray", 14), (4, "random", 14), (2, "random", 14), (4, "ray", 19), (4, "ray-one-corner", 14)])
+def test_grid_backward_lds_path_against_oracle(C, order, log2):
     """`nlr_grid_bwd_lds_kernel` (dense levels accumulated in an LDS copy of the table, taken when B * C >= 2^18: every real training
     step) against the C restatement of kernel_grid_backward (gridencoder.cu:248-340).  Ray-ordered points (runs of equal cells, the
-    run-length aggregation of the non-LDS levels) and random points (the large-B path had only been compared with itself)."""
-    L, H, log2 = 6, 16, 14
+    run-length aggregation of the non-LDS levels) and random points (the large-B path had only been compared with itself).
+    C = 4 leaves through `nlr_grid_bwd_xpair_kernel` (both x-corners of a cell edge per atomic instruction; hashed levels at 2^14 entries,
+    dense 33^3 / 65^3 levels beyond the LDS copy at 2^19) and, with NLR_DBG_NO_XPAIR_SCATTER, through the one-corner kernel of round 3."""
+    L, H = 6, 16
+    one_corner = order == "ray-one-corner"
+    order = "ray" if one_corner else order
     from nerflidar_hip import weights as nw
     offsets, sizes = nw.level_table(L, H, log2)[:2]
     B = (1 << 18) // C + 4096 + 37           # B * C >= 2^18, not a multiple of anything
@@ -218,9 +222,13 @@ def test_grid_backward_lds_path_against_oracle(C, order):
     off = np.ascontiguousarray(offsets, np.int32)
     gt = torch.zeros(n_entries, C, device=DEV)
     xd, gd = cu(x), cu(grad)
-    _lib.check(_lib.lib().nlr_grid_encode_backward(_lib.ptr(gd), _lib.ptr(xd), off.ctypes.data, _lib.ptr(gt), B, 3, C, L, 1.0, H, None, None,
-                                                   0, 0, 0, 0, None))
-    torch.cuda.synchronize()
+    try:
+        _lib.lib().nlr_debug_set(_lib.DBG_NO_XPAIR_SCATTER, int(one_corner))
+        _lib.check(_lib.lib().nlr_grid_encode_backward(_lib.ptr(gd), _lib.ptr(xd), off.ctypes.data, _lib.ptr(gt), B, 3, C, L, 1.0, H, None, None,
+                                                       0, 0, 0, 0, None))
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().nlr_debug_set(_lib.DBG_NO_XPAIR_SCATTER, 0)
     got = npy(gt)
     # float atomics (LDS and global) add in a different order than the oracle's sequential loop: tolerance relative to the sum of
     # |contributions| of a cell, which for the hot cells of level 0 is thousands of terms
