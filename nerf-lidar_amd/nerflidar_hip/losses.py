@@ -120,31 +120,44 @@ def data_loss(renderings: Sequence[Dict[str, torch.Tensor]], rgb: torch.Tensor, 
             e = sq
         else:
             raise ValueError(f"data_loss_type {kind!r} is not supported (charb, mse)")
-        per_level.append((m * e).sum() / denom if float(denom) > 0 else sq.sum() * 0)
+        per_level.append((m * e).sum() / denom.clamp_min(1))        # (an empty mask: 0 / 1, as the reference's guard; no host read of denom)
     return coarse_mult * sum(per_level[:-1]) + mult * per_level[-1]
 
 
+# The masked terms below select with `torch.where` and divide by the mask count instead of indexing with a boolean mask: `x[mask]` has a
+# data-dependent shape, i.e. a device-to-host read in the middle of every training step.  Same values up to the order of a float32 sum.
 def depth_loss(depth: torch.Tensor, target: torch.Tensor, mask: torch.Tensor, lam: float = 0.1) -> torch.Tensor:
     """train.py:330-341: log(|d| + 1) averaged over the residuals BELOW the 0.9 quantile of |d| (the comparison is on the signed
-    residual, as in the reference: every negative residual stays in)."""
-    d = depth[mask] - target[mask]
-    if d.numel() == 0:
-        return depth.sum() * 0
-    thr = torch.quantile(d.abs(), 0.9)
-    return lam * torch.log(d[d < thr].abs() + 1).mean()
+    residual, as in the reference: every negative residual stays in).  The quantile is torch.quantile's (linear interpolation between
+    the two neighbouring order statistics, rank 0.9 (n - 1) in float32) taken from a sort with the unmasked rays pushed to +inf."""
+    d = (depth - target).reshape(-1)
+    mask = mask.reshape(-1)
+    cnt = mask.sum()
+    srt = torch.sort(torch.where(mask, d.detach().abs(), torch.full_like(d, float("inf")))).values
+    pos = (cnt - 1).clamp_min(0).to(d.dtype) * 0.9                    # (a Python scalar: a device tensor made from one is a host copy)
+    lo = pos.floor()
+    pick = lambda i: srt.gather(0, i.long().reshape(1))[0]             # (srt[tensor_index] would read the index back to the host)
+    thr = torch.lerp(pick(lo), pick(pos.ceil()), pos - lo)
+    sel = mask & (d < thr)
+    # no masked ray: 0 (the reference's `numel() == 0` guard); masked rays but none below the quantile: 0 / 0, as `mean()` of nothing
+    n_sel = torch.where(cnt > 0, sel.sum(), torch.ones_like(cnt)).to(d.dtype)
+    return lam * torch.where(sel, torch.log(d.abs() + 1), torch.zeros_like(d)).sum() / n_sel
 
 
 def semantic_loss(prob: torch.Tensor, label: torch.Tensor, mask: torch.Tensor, lam: float = 0.01) -> torch.Tensor:
     """train.py:407-418: NLL of log(p + 1e-6) on the labelled rays."""
-    if int(mask.sum()) == 0:
-        return prob.sum() * 0
-    return lam * torch.nn.functional.nll_loss(torch.log(prob[mask] + 1e-6), label[mask].long())
+    K = prob.shape[-1]
+    prob, mask = prob.reshape(-1, K), mask.reshape(-1)
+    lab = torch.where(mask, label.reshape(-1).long(), torch.zeros_like(label.reshape(-1).long())).clamp(0, K - 1)
+    lp = torch.log(prob + 1e-6).gather(1, lab[:, None])[:, 0]
+    return -lam * torch.where(mask, lp, torch.zeros_like(lp)).sum() / mask.sum().clamp_min(1)
 
 
 def intensity_loss(pred: torch.Tensor, target: torch.Tensor, lidar_mask: torch.Tensor) -> torch.Tensor:
     """train.py:419-424: mean squared error on the LiDAR rays, x 0.1."""
-    d = (pred.reshape(-1) - target.reshape(-1))[lidar_mask.reshape(-1)]
-    return 0.1 * d.pow(2).mean() if d.numel() else pred.sum() * 0
+    d = pred.reshape(-1) - target.reshape(-1)
+    m = lidar_mask.reshape(-1)
+    return 0.1 * torch.where(m, d.pow(2), torch.zeros_like(d)).sum() / m.sum().clamp_min(1)
 
 
 def nusc_masks(batch: Dict[str, torch.Tensor], lidar_supervision: bool = False, only_lidar_supervision: bool = False,

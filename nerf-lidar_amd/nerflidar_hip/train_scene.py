@@ -78,10 +78,10 @@ def main(argv=None) -> int:
         batch = nscene.supervise(nscene.random_lidar_rays(a.rays, a.seed, step, dev, a.seed, a.scale_factor), a.seed, a.scale_factor)
         train_frac = float(np.clip((step - 1) / max(a.steps - 1, 1), 0, 1))  # train.py:184
         terms = ntrain.training_step(tm, opt, batch, train_frac=train_frac, randomized=True, hash_decay_mult=a.hash_decay,
-                                     depth_lam=a.depth_lam, sem_lam=a.sem_lam)
-        if step % a.log_every == 0 or step == 1 or step == a.steps:
+                                     depth_lam=a.depth_lam, sem_lam=a.sem_lam, as_tensors=True)
+        if step % a.log_every == 0 or step == 1 or step == a.steps:          # the only host read of the loop
             torch.cuda.synchronize()
-            rec = dict(step=step, lr=lr_fn(step), elapsed_s=round(time.time() - t0, 1), **{k: round(v, 6) for k, v in terms.items()})
+            rec = dict(step=step, lr=lr_fn(step), elapsed_s=round(time.time() - t0, 1), **{k: round(float(v), 6) for k, v in terms.items()})
             log.append(rec)
             print(json.dumps(rec), flush=True)
         if a.eval_every and step % a.eval_every == 0 and step < a.steps:

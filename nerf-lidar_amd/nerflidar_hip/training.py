@@ -90,6 +90,8 @@ def volumetric_render(density, tdist, dirs, rgbs, semantic=None, intensity=None,
 
 
 class _HashDecay(torch.autograd.Function):
+    _rows: Dict = {}
+
     @staticmethod
     def forward(ctx, embeddings, offsets_host):
         if not embeddings.is_cuda:
@@ -101,7 +103,10 @@ class _HashDecay(torch.autograd.Function):
         with torch.cuda.device(e.device):
             rc = _lib.lib().nlr_hash_decay_forward(_lib.ptr(e), off.ctypes.data_as(C.c_void_p), L, Cc, _lib.ptr(ss), _lib.current_stream())
         _lib.check(rc, "nlr_hash_decay_forward")
-        rows = torch.from_numpy(np.diff(off).astype(np.float64)).to(e.device)
+        key = (off.tobytes(), e.device)
+        rows = _HashDecay._rows.get(key)                                   # (uploaded once: a host copy per step is a synchronisation)
+        if rows is None:
+            rows = _HashDecay._rows[key] = torch.from_numpy(np.diff(off).astype(np.float64)).to(e.device)
         ctx.save_for_backward(e)
         ctx.off = off
         return (ss / rows.clamp_min(1)).sum().div(L * Cc).float()
@@ -112,10 +117,10 @@ class _HashDecay(torch.autograd.Function):
         off = ctx.off
         grad = torch.zeros_like(e)
         with torch.cuda.device(e.device):
-            rc = _lib.lib().nlr_hash_decay_backward(_lib.ptr(e), off.ctypes.data_as(C.c_void_p), len(off) - 1, e.shape[1], float(g),
+            rc = _lib.lib().nlr_hash_decay_backward(_lib.ptr(e), off.ctypes.data_as(C.c_void_p), len(off) - 1, e.shape[1], 1.0,
                                                     _lib.ptr(grad), _lib.current_stream())
         _lib.check(rc, "nlr_hash_decay_backward")
-        return grad, None
+        return grad.mul_(g), None   # (the upstream scalar stays on the device: float(g) would be a host read in every step)
 
 
 def hash_decay_loss(encoders, mult: float = 1.0) -> torch.Tensor:
@@ -823,10 +828,12 @@ def create_optimizer(model: torch.nn.Module, lr_init: float = 0.01, lr_final: fl
 
 def training_step(model: TrainableModel, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], train_frac: float = 1.0,
                   randomized: bool = True, hash_decay_mult: float = 0.1, tv_weight: float = 0.0, grad_max_norm: float = 0.0,
-                  grad_max_val: float = 0.0, latent_reg: float = 0.001, **loss_kw) -> Dict[str, float]:
+                  grad_max_val: float = 0.0, latent_reg: float = 0.001, as_tensors: bool = False, **loss_kw):
     """One optimiser step as train.py:272-459 takes it: forward with random jitter, the loss dictionary (`losses.total_loss` +
     hash decay), backward through the HIP backward kernels, optional total-variation gradient on the tables (grid.py:176-198),
-    gradient clipping incl. the unconditional nan_to_num_ (train_utils.clip_gradients), step.  Returns the loss terms as floats."""
+    gradient clipping incl. the unconditional nan_to_num_ (train_utils.clip_gradients), step.  Returns the loss terms as floats, or
+    with `as_tensors` as detached device scalars: reading them is the only host synchronisation of a step (without object tracks), so a
+    loop that logs every n-th step keeps the next step's launches ahead of the GPU in between."""
     from . import losses as nlosses
     optimizer.zero_grad(set_to_none=True)
     renderings, history = model(batch, train_frac=train_frac, randomized=randomized)
@@ -842,6 +849,6 @@ def training_step(model: TrainableModel, optimizer: torch.optim.Optimizer, batch
             lv.encoder.grad_total_variation(tv_weight)
     clip_gradients(model, grad_max_norm, grad_max_val)
     optimizer.step()
-    out = {k: float(v.detach()) for k, v in terms.items()}
-    out["loss"] = float(loss.detach())
-    return out
+    out = {k: v.detach() for k, v in terms.items()}
+    out["loss"] = loss.detach()
+    return out if as_tensors else {k: float(v) for k, v in out.items()}

@@ -23,8 +23,8 @@ for g in opt.param_groups:
     g["lr"] = 1e-4                                                # late in a run: the field stays the scene it is
 sf = 1.0 / 250.0
 def draw(step): return nscene.supervise(nscene.random_lidar_rays(rays, 0, step, dev, 0, sf), 0, sf)
-def step(i, batch=None):
-    return ntrain.training_step(tm, opt, batch if batch is not None else draw(i), train_frac=0.9, randomized=True, hash_decay_mult=0.1)
+def step(i, batch=None, as_tensors=True):
+    return ntrain.training_step(tm, opt, batch if batch is not None else draw(i), train_frac=0.9, randomized=True, hash_decay_mult=0.1, as_tensors=as_tensors)
 for i in range(5): out = step(i)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = 10
@@ -36,8 +36,12 @@ torch.cuda.synchronize(); dt_draw = (time.perf_counter() - t0) / K
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(K): out = step(0, b)
 torch.cuda.synchronize(); dt_fixed = (time.perf_counter() - t0) / K
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(K): step(0, b, as_tensors=False)
+torch.cuda.synchronize(); dt_read = (time.perf_counter() - t0) / K
 print(f"{summ['workload']} trained checkpoint, maps 2^{log2}, {rays} rays x {mc.level_samples()} samples: {dt*1e3:.1f} ms per step incl. drawing + supervising the rays "
-      f"({dt_draw*1e3:.1f} ms of it), {dt_fixed*1e3:.1f} ms on a batch already drawn -> {rays/dt_fixed/1e3:.0f} k rays/s; loss {out['loss']:.5f}")
+      f"({dt_draw*1e3:.1f} ms of it), {dt_fixed*1e3:.1f} ms on a batch already drawn -> {rays/dt_fixed/1e3:.0f} k rays/s "
+      f"({dt_read*1e3:.1f} ms when every step reads its loss terms back); loss {float(out['loss']):.5f}")
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for i in range(3): step(0, b)

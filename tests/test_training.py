@@ -443,6 +443,31 @@ def test_training_step_of_the_whole_model(fused):
 
 
 @pytest.mark.gpu
+def test_training_step_reads_nothing_back_until_its_terms_are_asked_for():
+    """A step of the static model (forward, `losses.total_loss` with every masked term, hash decay, backward, clip, Adam) under
+    `torch.cuda.set_sync_debug_mode("error")`: any device-to-host read inside it (a boolean-mask index, `float(tensor)`, `nonzero`) raises.
+    `training_step(..., as_tensors=True)` hands the terms back as device scalars; a training loop reads them only when it logs."""
+    from nerflidar_hip import scene as nscene
+    mc, sd, _ = _ref_scene()
+    mc.config.use_intensity = True
+    mc.__post_init__()
+    from nerflidar_hip import weights as nweights
+    tm = ntrain.TrainableModel(mc, fused_mlp=True).cuda().load_reference(nweights.synth_state_dict(mc, seed=0, trained_like=True))
+    opt = torch.optim.Adam(tm.parameters(), lr=1e-3, eps=1e-15)
+    batch = nscene.supervise(nscene.random_lidar_rays(2048, 0, 1, torch.device("cuda")))
+    first = ntrain.training_step(tm, opt, batch)                      # warm-up: lazy initialisations may read back
+    assert set(first) >= {"data", "depth", "sem", "int", "loss"} and all(np.isfinite(v) for v in first.values())
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = ntrain.training_step(tm, opt, batch, as_tensors=True)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert all(isinstance(v, torch.Tensor) and v.is_cuda and v.dim() == 0 for v in out.values())
+    assert np.isfinite(float(out["loss"]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fused", [False, True])
 def test_whole_training_step_matches_the_reference_step(fused):
     """The reference's WHOLE step on one batch - `model(...)` in training mode, the loss assembly of train.py:283-453 (executed from the
