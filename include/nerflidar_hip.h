@@ -241,8 +241,8 @@ const char *nlr_build_sha(void);
  *   NLR_DBG_MLP_WORKGROUPS (key 1): n > 0 caps the persistent MLP grid of models created AFTERWARDS at n workgroups (power / clock
  *     experiments, profiles/r03_mlp_cu_sweep.txt).
  *   NLR_DBG_BINNED_C4 (key 2): 1 lets the binned scatter (nlr_grid_encode_backward_ws) take level_dim = 4 grids as well (A/B only).
- *   NLR_DBG_NO_XPAIR_SCATTER (key 3): 1 sends the level_dim = 4 atomic scatter through the one-corner-per-instruction kernel of rounds
- *     2-3 (nlr_grid_bwd_kernel<4>) instead of nlr_grid_bwd_xpair_kernel<4> (A/B only; same sums up to the order of the atomics).
+ *   NLR_DBG_NO_XPAIR_SCATTER (key 3): 1 sends the atomic scatter of level_dim <= 4 grids through the one-corner-per-instruction kernel of
+ *     rounds 2-3 (nlr_grid_bwd_kernel) instead of nlr_grid_bwd_xpair_kernel (A/B only; same sums up to the order of the atomics).
  *   NLR_DBG_SCATTER_LEVELS (key 4): a non-zero bit mask restricts nlr_grid_bwd_xpair_kernel to the levels whose bit is set (per-level
  *     timing, scripts/train_scene_profile.py; the gradient of the other levels is then NOT written).
  *   NLR_DBG_NO_SCATTER_CACHE (key 5): 1 keeps the coarse levels beyond the LDS copy (up to 128^3 cells) out of the tagged LDS cache of

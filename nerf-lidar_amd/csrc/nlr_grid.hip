@@ -747,20 +747,23 @@ static int nlr_grid_backward_impl(const float *grad, const float *inputs, const 
         NLR_LAUNCH_CHECK("nlr_grid_bwd_bin_kernel / nlr_grid_bwd_acc_kernel");
     } else if (nscat) {
         dim3 grid((unsigned)(((size_t)B * C + 255) / 256), nscat);  // one lane per (point, channel)
+        // both x-corners per atomic instruction (twice the waves, half the instructions each) unless the A/B switch asks for round 3's kernel
+        const bool xpair = C <= 4 && !nlr_debug_get(NLR_DBG_NO_XPAIR_SCATTER);
+        if (xpair) NLR_CHECK_ARG((uint64_t)B * 2 * C < (1ull << 32), "grid_encode_backward: B = %u points do not fit the 32-bit lane index of the x-pair scatter", B);
+        dim3 gridx((unsigned)(((size_t)B * 2 * C + 255) / 256), nscat);
+        const uint32_t lvmask = (uint32_t)nlr_debug_get(NLR_DBG_SCATTER_LEVELS);
+#define NLR_SCATTER_LAUNCH(CC)                                                                                                                    \
+    do {                                                                                                                                          \
+        if (xpair) hipLaunchKernelGGL(nlr_grid_bwd_xpair_kernel<CC>, gridx, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list, lvmask); \
+        else hipLaunchKernelGGL(nlr_grid_bwd_kernel<CC>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list);        \
+    } while (0)
         switch (C) {
-            case 1: hipLaunchKernelGGL(nlr_grid_bwd_kernel<1>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list); break;
-            case 2: hipLaunchKernelGGL(nlr_grid_bwd_kernel<2>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list); break;
-            case 4:
-                if (nlr_debug_get(NLR_DBG_NO_XPAIR_SCATTER)) {
-                    hipLaunchKernelGGL(nlr_grid_bwd_kernel<4>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list);
-                } else {  // 8 points per wave: twice the waves, half the atomic instructions each
-                    NLR_CHECK_ARG((uint64_t)B * 8 < (1ull << 32), "grid_encode_backward: B = %u points do not fit the 32-bit lane index of the x-pair scatter", B);
-                    hipLaunchKernelGGL(nlr_grid_bwd_xpair_kernel<4>, dim3((unsigned)(((size_t)B * 8 + 255) / 256), nscat), block, 0, st, grad, inputs, gp,
-                                       grad_embeddings, B, grad_layout, level_list, (uint32_t)nlr_debug_get(NLR_DBG_SCATTER_LEVELS));
-                }
-                break;
+            case 1: NLR_SCATTER_LAUNCH(1); break;
+            case 2: NLR_SCATTER_LAUNCH(2); break;
+            case 4: NLR_SCATTER_LAUNCH(4); break;
             default: hipLaunchKernelGGL(nlr_grid_bwd_kernel<8>, grid, block, 0, st, grad, inputs, gp, grad_embeddings, B, grad_layout, level_list); break;
         }
+#undef NLR_SCATTER_LAUNCH
         NLR_LAUNCH_CHECK("nlr_grid_bwd_kernel");
     }
     if (dy_dx) {

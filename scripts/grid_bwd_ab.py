@@ -89,3 +89,31 @@ def run_xpair(name, C, Lv, desired, S, spread):
           f"max |difference| / max |gradient| {err:.1e}")
 
 run_xpair("NerfMLP grid (res 8192), 65 536 rays x 32 samples", 4, 10, 8192, 32, 0.002)
+
+
+def run_xpair_c1(name, Lv, desired, S, spread):
+    """The C = 1 atomic scatter (the path without a workspace): x-pair layout against the one-corner kernel."""
+    import math
+    x = points(S, spread)
+    B = x.shape[0]
+    offsets, sizes, pls = nw.level_table(Lv, 16, 21, desired_resolution=desired)
+    off = torch.from_numpy(np.ascontiguousarray(offsets, np.int32))
+    g = torch.randn(B, Lv, device=dev)
+    out = {}
+    for tag, key in (("one corner", 1), ("x-pair", 0)):
+        L_.nlr_debug_set(_lib.DBG_NO_XPAIR_SCATTER, key)
+        gt = torch.zeros(int(offsets[-1]), 1, device=dev)
+        def call():
+            _lib.check(L_.nlr_grid_encode_backward(_lib.ptr(g), _lib.ptr(x), _lib.ptr(off), _lib.ptr(gt), B, 3, 1, Lv, float(math.log2(pls)), 16, None, None, 0, 0, 0, 1, None))
+        call(); torch.cuda.synchronize()
+        out[tag] = gt.clone()
+        t0 = time.perf_counter()
+        for _ in range(5): call()
+        torch.cuda.synchronize()
+        out[tag + "_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+    L_.nlr_debug_set(_lib.DBG_NO_XPAIR_SCATTER, 0)
+    err = (out["one corner"] - out["x-pair"]).abs().max().item() / max(out["one corner"].abs().max().item(), 1e-9)
+    print(f"{name}: C=1, L={Lv}, no workspace: one corner per atomic instruction {out['one corner_ms']:.2f} ms, both x-corners {out['x-pair_ms']:.2f} ms, max |difference| / max |gradient| {err:.1e}")
+
+run_xpair_c1("proposal grid 0 (res 512)", 6, 512, 64, 0.01)
+run_xpair_c1("proposal grid 1 (res 2048)", 8, 2048, 64, 0.004)
