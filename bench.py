@@ -75,6 +75,9 @@ def parse_args(argv=None):
                     "renders synthetic_sweep(sweep_idx = i mod 64) from pre-uploaded ray batches, as a LiDAR replay moves the sensor every "
                     "sweep (Z/train.py:484-485 counts rays of distinct batches), so the caches hold what a replay leaves, not the "
                     "previous step's identical access pattern")
+    ap.add_argument("--ray-groups", choices=["auto", "rays", "samples"], default="auto", help="A/B: which samples share a wave of the encode kernels. auto "
+                    "(default): decided per level on the device from the coherence of adjacent rays' samples; rays: always 8 adjacent rays x one "
+                    "sample index; samples: always 8 consecutive samples of one ray (rounds 1-3) (nlr_debug_set NLR_DBG_RAY_GROUPS)")
     ap.add_argument("--selftest-cpu", action="store_true", help="launcher + partition + collective logic on CPU (gloo) with a "
                     "stand-in renderer; for tests/, measures nothing")
     ap.add_argument("--selftest-hw", type=int, nargs=2, default=[4, 64], metavar=("H", "W"),
@@ -356,6 +359,7 @@ def main():
         if args.weight_scale is not None:
             sd = {k: (v * np.float32(args.weight_scale) if v.dtype == np.float32 else v) for k, v in sd.items()}
     model = Model(mc, sd, device=dev, precision=args.precision, table_dtype=tdt)
+    _lib.lib().nlr_debug_set(_lib.DBG_RAY_GROUPS, {"auto": 0, "rays": 1, "samples": 2}[args.ray_groups])
     width = args.width * (world if args.scaling == "weak" else 1)
     emul = args.emulate_world if (args.emulate_world > 1 and world == 1) else 0
     n_sweeps = 1 if args.static_origin else 64
@@ -476,7 +480,7 @@ def main():
         prof = os.path.join(ROOT, "profiles", PMC_PROFILE)
         plain = (world == 1 and args.workload == "C2" and not args.chunk and not emul and args.width == W_COLS and args.table_dtype == "f32"
                  and args.precision == 2 and args.log2_hashmap is None and not args.ckpt and not args.static_origin and args.weight_scale is None
-                 and not args.mlp_workgroups)
+                 and not args.mlp_workgroups and args.ray_groups == "auto")
         traffic, tnote = pmc_traffic(prof, bsha, ssha, "nlr_mlp_kernel", plain)
         # second ceiling: the gather side, priced in bytes that really cross the L2's memory-side port.  achieved = PMC counter
         # bytes per launch (FETCH_SIZE [x 1 for these random-line kernels, see scripts/pmc_traffic.sh] + WRITE_SIZE; the committed profile of THIS binary) / the
@@ -549,7 +553,8 @@ def main():
                                            "2 056 TFLOP/s at 2.39 GHz on all-zero operands): profiles/r04_power_trace.txt"},
             "roofline_gather": rg,
             "roofline_prop": rp,
-            "debug_switches": {"force_generic_level_body": L.nlr_debug_get(_lib.DBG_FORCE_GENERIC), "mlp_workgroups": L.nlr_debug_get(_lib.DBG_MLP_WORKGROUPS)},
+            "debug_switches": {"force_generic_level_body": L.nlr_debug_get(_lib.DBG_FORCE_GENERIC), "mlp_workgroups": L.nlr_debug_get(_lib.DBG_MLP_WORKGROUPS),
+                               "ray_groups": L.nlr_debug_get(_lib.DBG_RAY_GROUPS)},
             "kernel_source_sha": bsha[:16],
             "binary_stale": buildinfo.stale(),
         }

@@ -187,6 +187,12 @@ typedef struct NlrRenderCfg {
     const float *rand_jitter[NLR_MAX_LEVELS];
     const float *rand_deg[NLR_MAX_LEVELS];
     float scale_factor;              /* >0: also emit points/labels (render_lidar.py:142-161) */
+    /* Performance hint, no effect on the results.  0 (sweeps in beam-major / azimuth-fastest order, images and tiles in row-major order):
+     * consecutive rays of the batch are neighbours in space; per level the library then counts on the device whether their samples are
+     * too (nlr_ray_vote_kernel) and lets a wave of the fused cast + encode kernels take either 8 ADJACENT rays at one sample index (a
+     * trained field: they gather the same table lines) or 8 consecutive samples of ONE ray.  1: the batch is shuffled (training-style
+     * random rays): always the latter, nothing is counted. */
+    uint32_t shuffled_rays;
 } NlrRenderCfg;
 
 typedef struct NlrLevelOut {         /* one ray_history entry (models.py:553-557); any may be NULL */
@@ -246,13 +252,16 @@ const char *nlr_build_sha(void);
  *   NLR_DBG_SCATTER_LEVELS (key 4): a non-zero bit mask restricts nlr_grid_bwd_xpair_kernel to the levels whose bit is set (per-level
  *     timing, scripts/train_scene_profile.py; the gradient of the other levels is then NOT written).
  *   NLR_DBG_NO_SCATTER_CACHE (key 5): 1 keeps the coarse levels beyond the LDS copy (up to 128^3 cells) out of the tagged LDS cache of
- *     nlr_grid_bwd_lds_kernel: they are scattered (atomics / bins) as in round 3 (A/B only; nlr_grid_backward_workspace_bytes follows). */
+ *     nlr_grid_bwd_lds_kernel: they are scattered (atomics / bins) as in round 3 (A/B only; nlr_grid_backward_workspace_bytes follows).
+ *   NLR_DBG_RAY_GROUPS (key 6): model renders normally decide per level on the device which samples share a wave of the encode kernels
+ *     (NlrRenderCfg.shuffled_rays); 1 forces 8 adjacent rays x one sample index, 2 forces 8 consecutive samples of one ray (A/B only). */
 #define NLR_DBG_FORCE_GENERIC 0
 #define NLR_DBG_MLP_WORKGROUPS 1
 #define NLR_DBG_BINNED_C4 2
 #define NLR_DBG_NO_XPAIR_SCATTER 3
 #define NLR_DBG_SCATTER_LEVELS 4
 #define NLR_DBG_NO_SCATTER_CACHE 5
+#define NLR_DBG_RAY_GROUPS 6
 int nlr_debug_set(uint32_t key, int value);
 int nlr_debug_get(uint32_t key);
 /* 1 when the fused kernels' fast level body covers this grid (see csrc/nlr_level_fast.h:nlr_level_fast_ok), 0 when the generic body

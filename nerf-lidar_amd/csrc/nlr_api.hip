@@ -490,7 +490,7 @@ static size_t level_ws(const LevelModel &lv, uint32_t N, bool last) {
 
 extern "C" size_t nlr_workspace_bytes(const NlrModel *m, uint32_t N) {
     if (!m) return 0;
-    size_t b = 256;
+    size_t b = 256 + al(64 * sizeof(uint32_t));  // (+ the per-level vote counters of render_impl)
     for (uint32_t l = 0; l < m->num_levels; ++l) b += level_ws(m->lv[l], N, l + 1 == m->num_levels);
     return b;
 }
@@ -500,12 +500,15 @@ extern "C" size_t nlr_workspace_bytes(const NlrModel *m, uint32_t N) {
 static int run_mlp_level(const NlrModel *m, const LevelModel &lv, const NlrRays *rays, const float *tdist, uint32_t N,
                          uint32_t n, uint32_t mloops, const float *rand_deg, float *feat, float *raybias, float *density,
                          float *rgb, float *sem, float *inten, float *prop_feat, hipStream_t st, bool internal_feat = false,
-                         float *seg = nullptr, float *dnorm = nullptr) {
+                         float *seg = nullptr, float *dnorm = nullptr, uint32_t ray_groups = 0, const uint32_t *votes = nullptr) {
     // features in the workspace (never seen by the caller) take the piece-major layout when the fast kernels apply
     const int piece_major = (internal_feat && !lv.is_prop && n <= 8 && lv.F % 4 == 0) ? 1 : 0;  // any level_dim in {1, 2, 4, 8}: nlr_feat_ptr
     CastParams cp;
     int rc = nlr_fill_cast_params(&cp, rays, tdist, rand_deg, N, lv.S, n, mloops, m->std_scale);
     if (rc) return rc;
+    cp.ray_groups = ray_groups;  // (nlr_kernels.h: which samples share a wave of the fused cast + encode kernels)
+    cp.votes = votes;
+    cp.vote_min = (uint32_t)(((uint64_t)(N ? N - 1 : 0) * lv.S) / 2);
     if (lv.is_prop) {
         ProfScope ps(&m->prof, NLR_K_PROP, st);
         return nlr_launch_prop(cp, lv.gp, lv.p_w1, lv.p_b1, lv.p_w2, lv.p_b2, lv.density_bias, lv.re_weights, density, prop_feat, st);
@@ -608,6 +611,8 @@ static int render_impl(const NlrModel *m, const NlrRays *rays, uint32_t N, const
     void *obj_space = dyn ? (char *)workspace + (workspace_bytes - obj_ws) : nullptr;  // the tail of the workspace
     Carve c(workspace, workspace_bytes - obj_ws);
     const uint32_t n = cfg->sample_n ? cfg->sample_n : 7, mloops = cfg->sample_m ? cfg->sample_m : 3;
+    uint32_t *votes = (uint32_t *)c.take(64);  // per level: coherent (adjacent rays, sample) pairs, see nlr_slot_sample
+    NLR_HIP(hipMemsetAsync(votes, 0, 64 * sizeof(uint32_t), st));
 
     const float *prev_s = nullptr, *prev_w = nullptr;
     uint32_t n_prev = 0;
@@ -652,8 +657,14 @@ static int render_impl(const NlrModel *m, const NlrRays *rays, uint32_t N, const
                 inten = lv.use_int ? (ho.intensity ? ho.intensity : c.take((size_t)N * S)) : nullptr;
             }
         }
+        // which samples share a wave of the encode kernels: consecutive rays of a sweep / an image tile are neighbours in space, and whether
+        // their samples are depends on the field - counted here per level unless the caller says the batch is shuffled
+        uint32_t groups = cfg->shuffled_rays ? 0u : 2u;
+        if (const int force = nlr_debug_get(NLR_DBG_RAY_GROUPS)) groups = force == 1 ? 1u : 0u;
+        if (groups == 2u && n > 8) groups = 0u;  // (the sample-parallel kernels of sample_n > 8 have one order)
+        if (groups == 2u && (rc = nlr_launch_ray_vote(tdist, N, S, votes + l, st))) return rc;
         rc = run_mlp_level(m, lv, rays, tdist, N, n, mloops, cfg->rand_deg[l], feat, rb, density, rgb, sem, inten, nullptr, st, true, seg,
-                           dnorm);
+                           dnorm, groups, votes + l);
         if (rc) return rc;
         if (dyn) {  // (the object networks have no intensity head: DynamicModel refuses use_intensity, like the reference's merge)
             rc = nlr_objects_apply_impl(dyn->objs, rays, tdist, dyn->box_params, N, S, dyn->n_obj, density, rgb, sem, lv.K,

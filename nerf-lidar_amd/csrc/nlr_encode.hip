@@ -172,6 +172,66 @@ __global__ void __launch_bounds__(256) nlr_prop_kernel(CastParams cp, GridParams
     density[m] = x > 20.0f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20), models.py:1116
 }
 
+// Slot -> sample.  The fused kernels give 8 lanes (one per multisample) to a SLOT and 8 consecutive slots to a wave; which sample a slot
+// is decides what a wave's 56 points have in common.
+//   sample-major: slot = ray * S + k - a wave holds 8 consecutive samples of ONE ray.  Where the proposal chain piles a ray's samples up
+//     (white-noise weights: every ray is absorbed within a few cells, at a depth unrelated to its neighbour's) they share their cells.
+//   ray groups: inside a group of 8 consecutive rays the slots run ray-fastest, slot = (ray / 8) * 8 S + k * 8 + ray % 8 - a wave holds
+//     8 ADJACENT rays at one sample index.  On a trained field the samples of a ray are metres apart (median interval 1.7 m) while
+//     azimuth neighbours 0.18 m apart at 30 m meet the same surface at the same index: the table lines a wave gathers on the hashed
+//     levels are shared.  Trained scene: encode 4.67 -> 3.37 ms, proposal 0.89 -> 0.60 ms; white noise: encode 1.33 -> 1.75 ms
+//     (profiles/r04_ray_groups_ab.txt).
+// Neither is right for every field, so a model render decides per level ON THE DEVICE (ray_groups = 2): nlr_ray_vote_kernel counts the
+// (adjacent rays, sample index) pairs whose k-th samples lie within one interval of each other, and every workgroup of the encode launch
+// reads the count.  Same arithmetic per sample either way: bit-identical features.  Rays beyond N (the last group of a ray count that is
+// not a multiple of 8) are slots without a sample.
+__device__ __forceinline__ bool nlr_slot_sample(const CastParams &cp, uint32_t slot, uint32_t &ray, uint32_t &k) {
+    const bool groups = cp.ray_groups == 1u || (cp.ray_groups == 2u && cp.votes[0] > cp.vote_min);
+    if (groups) {
+        const uint32_t G = 8u * cp.S, gi = slot / G, w = slot - gi * G;
+        ray = gi * 8u + (w & 7u);
+        k = w >> 3;
+    } else {
+        ray = slot / cp.S;
+        k = slot - ray * cp.S;
+    }
+    const bool in = ray < cp.N;
+    if (!in) ray = cp.N - 1, k = cp.S - 1;   // (a harmless sample for the loads of a lane that contributes nothing)
+    return in;
+}
+// (ray r, sample k), r < N - 1: does ray r + 1 put its k-th sample within ray r's k-th interval of it?  A fixed grid strides over the
+// pairs and every workgroup adds its count once: atomics on ONE address queue at ~40 cycles each (profiles/r04_atomic_microbench.txt) -
+// one per wave made this kernel 1.2 ms long.
+__global__ void __launch_bounds__(256) nlr_ray_vote_kernel(const float *__restrict__ tdist, uint32_t N, uint32_t S, uint32_t *__restrict__ votes) {
+    __shared__ uint32_t part[4];
+    const uint32_t total = (N - 1) * S;
+    uint32_t mine = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t r = i / S, k = i - r * S;
+        const float *a = tdist + (size_t)r * (S + 1) + k;
+        mine += fabsf(a[S + 1] - a[0]) < (a[1] - a[0]) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t c = part[0] + part[1] + part[2] + part[3];
+        if (c) atomicAdd(votes, c);
+    }
+}
+int nlr_launch_ray_vote(const float *tdist, uint32_t N, uint32_t S, uint32_t *votes, hipStream_t st) {
+    if (N < 2 || S == 0) return NLR_OK;
+    NLR_CHECK_ARG((uint64_t)N * S < (1ull << 32), "ray vote: N * S = %llu does not fit 32 bits", (unsigned long long)N * S);
+    const uint32_t nb = ((N - 1) * S + 255) / 256;
+    hipLaunchKernelGGL(nlr_ray_vote_kernel, dim3(nb < 512u ? nb : 512u), dim3(256), 0, st, tdist, N, S, votes);
+    NLR_LAUNCH_CHECK("nlr_ray_vote_kernel");
+    return NLR_OK;
+}
+__host__ __forceinline__ uint64_t nlr_slot_count(const CastParams &cp) {
+    return (uint64_t)(cp.ray_groups ? (cp.N + 7u) / 8u * 8u : cp.N) * cp.S;
+}
+
 // =============================================================================================================
 // Multisample-parallel variants (sample_n <= 8): one lane per (sample, multisample), 8 lanes per sample.
 // Cone casting + contraction run ONCE per multisample (the (sample, level) mapping above repeats them per level),
@@ -211,12 +271,11 @@ __global__ void __launch_bounds__(256) nlr_encode8g_kernel(CastParams cp, GridPa
                                                           int piece_major) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = cp.N * cp.S;
-    uint32_t m = gt >> 3;
     const uint32_t j = gt & 7;
-    const bool in = m < M;
-    if (!in) m = M - 1;
+    uint32_t ray, k;
+    const bool in = nlr_slot_sample(cp, gt >> 3, ray, k);
+    const uint32_t m = ray * cp.S + k;
     const bool active = in && j < cp.n;
-    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
     float o[3], d[3], bx[3], by[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -267,13 +326,11 @@ __global__ void __launch_bounds__(256) nlr_prop8g_kernel(CastParams cp, GridPara
     }
     __syncthreads();
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t M = cp.N * cp.S;
-    uint32_t m = gt >> 3;
     const uint32_t j = gt & 7;
-    const bool in = m < M;
-    if (!in) m = M - 1;
+    uint32_t ray, k;
+    const bool in = nlr_slot_sample(cp, gt >> 3, ray, k);
+    const uint32_t m = ray * cp.S + k;
     const bool active = in && j < cp.n;
-    const uint32_t ray = m / cp.S, k = m - ray * cp.S;
     float o[3], d[3], bx[3], by[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -391,13 +448,12 @@ __device__ __forceinline__ void nlr_encode8_block(const CastParams &cp, const Gr
                                                   int piece_major, uint32_t block) {
     const uint32_t gt = block * 256u + threadIdx.x;
     const uint32_t M = cp.N * cp.S;
-    uint32_t m = gt >> 3;
     const uint32_t j = gt & 7;
-    const bool in = m < M;
-    if (!in) m = M - 1;
+    uint32_t pray, k;
+    const bool in = nlr_slot_sample(cp, gt >> 3, pray, k);
+    const uint32_t ray = NLR_DBG_RAY(pray);
+    const uint32_t m = ray * cp.S + k;
     const bool active = in && j < cp.n;
-    const uint32_t pray = m / cp.S, k = m - pray * cp.S, ray = NLR_DBG_RAY(pray);
-    m = ray * cp.S + k;
     const RayRegs rr = nlr_load_ray(cp, ray, k);
     const Gauss g = nlr_cast_one(cp, ray, k, active ? j : 0, rr.t0, rr.t1, rr.o, rr.d, rr.bx, rr.by, rr.radius);
     // gridencoder.cu:124-135: a point outside [0,1]^3 encodes as zeros on every level
@@ -457,14 +513,12 @@ __global__ void __launch_bounds__(256) nlr_prop8_kernel(CastParams cp, GridParam
     __syncthreads();
   for (uint32_t lb = blockIdx.x; lb < nblocks; lb += gridDim.x) {  // (one workgroup per 32 samples, or a persistent grid: see nlr_encode8_kernel)
     const uint32_t gt = (chunk ? nlr_xcd_block(lb, nblocks, chunk) : lb) * 256u + threadIdx.x;
-    const uint32_t M = cp.N * cp.S;
-    uint32_t m = gt >> 3;
     const uint32_t j = gt & 7;
-    const bool in = m < M;
-    if (!in) m = M - 1;
+    uint32_t pray, k;
+    const bool in = nlr_slot_sample(cp, gt >> 3, pray, k);
+    const uint32_t ray = NLR_DBG_RAY(pray);
+    const uint32_t m = ray * cp.S + k;
     const bool active = in && j < cp.n;
-    const uint32_t pray = m / cp.S, k = m - pray * cp.S, ray = NLR_DBG_RAY(pray);
-    m = ray * cp.S + k;
     const RayRegs rr = nlr_load_ray(cp, ray, k);
     const Gauss g = nlr_cast_one(cp, ray, k, active ? j : 0, rr.t0, rr.t1, rr.o, rr.d, rr.bx, rr.by, rr.radius);
     const bool valid = active && !((g.x0 < 0 || g.x0 > 1) || (g.x1 < 0 || g.x1 > 1) || (g.x2 < 0 || g.x2 > 1));
@@ -688,13 +742,13 @@ int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist
 // Diagnostic switches (include/nerflidar_hip.h: nlr_debug_set / nlr_debug_get): explicit and readable back; the library reads no
 // environment variable.  [0] force the generic level body, [1] cap of the persistent MLP grid for models created afterwards.
 #include <atomic>
-static std::atomic<int> nlr_debug_switch[6] = {{0}, {0}, {0}, {0}, {0}, {0}};
+static std::atomic<int> nlr_debug_switch[7] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}};
 extern "C" int nlr_debug_set(uint32_t key, int value) {
-    NLR_CHECK_ARG(key < 6, "debug_set: unknown key %u", key);
+    NLR_CHECK_ARG(key < 7, "debug_set: unknown key %u", key);
     nlr_debug_switch[key].store(value);
     return NLR_OK;
 }
-extern "C" int nlr_debug_get(uint32_t key) { return key < 6 ? nlr_debug_switch[key].load() : 0; }
+extern "C" int nlr_debug_get(uint32_t key) { return key < 7 ? nlr_debug_switch[key].load() : 0; }
 static bool nlr_force_generic() { return nlr_debug_switch[NLR_DBG_FORCE_GENERIC].load() != 0; }
 
 extern "C" int nlr_grid_fast_path(const int32_t *offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, int table_dtype, uint32_t gridtype,
@@ -723,11 +777,11 @@ int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights
     nlr_dbg_upload(st);
 #endif
     // 8 lanes per sample with a 32-bit lane index (the kernels compute N * S in 32 bits)
-    NLR_CHECK_ARG((uint64_t)cp.N * cp.S * 8 < (1ull << 32), "encode: N * S = %llu samples do not fit the 32-bit lane index (chunk the rays)",
+    NLR_CHECK_ARG(nlr_slot_count(cp) * 8 < (1ull << 32), "encode: N * S = %llu samples do not fit the 32-bit lane index (chunk the rays)",
                   (unsigned long long)cp.N * cp.S);
     const uint32_t M = cp.N * cp.S;
     if (cp.n <= 8) {  // multisample-parallel mapping
-        dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
+        dim3 grid8((uint32_t)((nlr_slot_count(cp) * 8 + 255) / 256)), block8(256);
         const bool fast = nlr_level_fast_ok(gp) && !nlr_force_generic();
         uint32_t chunk = NLR_XCD_CHUNK;
         dim3 gridp = grid8;
@@ -783,7 +837,7 @@ int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights
 
 int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1, const float *b1, const float *w2, float b2,
                     float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st) {
-    NLR_CHECK_ARG((uint64_t)cp.N * cp.S * 8 < (1ull << 32), "proposal level: N * S = %llu samples do not fit the 32-bit lane index (chunk the rays)",
+    NLR_CHECK_ARG(nlr_slot_count(cp) * 8 < (1ull << 32), "proposal level: N * S = %llu samples do not fit the 32-bit lane index (chunk the rays)",
                   (unsigned long long)cp.N * cp.S);
     const uint32_t M = cp.N * cp.S;
 #ifdef NLR_DBG_ENV
@@ -798,7 +852,7 @@ int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1,
     mp.F = gp.L * gp.C;
     NLR_CHECK_ARG(mp.F <= 16, "proposal MLP: L*C = %u > 16 features is outside the fused proposal kernel", mp.F);
     if (cp.n <= 8) {
-        dim3 grid8((uint32_t)(((size_t)M * 8 + 255) / 256)), block8(256);
+        dim3 grid8((uint32_t)((nlr_slot_count(cp) * 8 + 255) / 256)), block8(256);
         const bool fast = nlr_level_fast_ok(gp) && !nlr_force_generic();
         uint32_t chunk = NLR_XCD_CHUNK;
         dim3 gridp = grid8;

@@ -9,6 +9,11 @@ struct CastParams {
     const float *tdist;      // [N, S+1]
     const float *rand_deg;   // [N, S, n] uniform draws or null
     uint32_t N, S, n;        // rays, samples per ray, multisamples
+    // Which samples share a wave of the fused cast + encode kernels (nlr_encode.hip:nlr_slot_sample; no effect on the results):
+    // 0 = 8 consecutive samples of ONE ray, 1 = 8 ADJACENT rays at one sample index, 2 = decided on the device from `votes`
+    // (nlr_launch_ray_vote: 1 when more than vote_min of the (adjacent rays, sample) pairs are coherent).
+    uint32_t ray_groups, vote_min;
+    const uint32_t *votes;
     float std_scale;
     float cosd[NLR_MAX_MULTI], sind[NLR_MAX_MULTI];  // cos/sin(2*pi*m*j/n), render.py:148
     float degj[NLR_MAX_MULTI];                       // the angles themselves (rand path)
@@ -75,6 +80,7 @@ int nlr_fill_cast_params(CastParams *cp, const NlrRays *rays, const float *tdist
                          uint32_t S, uint32_t n, uint32_t mloops, float std_scale);
 // piece_major: features as [F/4][M][4] (only honoured by the 8-lane kernel with C == 4; see nlr_encode8_kernel)
 int nlr_launch_encode(const CastParams &cp, const GridParams &gp, int re_weights, float *feat, int piece_major, hipStream_t st);
+int nlr_launch_ray_vote(const float *tdist, uint32_t N, uint32_t S, uint32_t *votes, hipStream_t st);
 int nlr_launch_prop(const CastParams &cp, const GridParams &gp, const float *w1, const float *b1, const float *w2, float b2,
                     float density_bias, int re_weights, float *density, float *feat_out, hipStream_t st);
 int nlr_launch_direnc(const DirEncParams &P, hipStream_t st);

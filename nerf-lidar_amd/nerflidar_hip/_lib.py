@@ -62,7 +62,7 @@ class NlrRays(C.Structure):
 class NlrRenderCfg(C.Structure):
     _fields_ = [("train_frac", C.c_float), ("compute_extras", C.c_uint32), ("sample_n", C.c_uint32),
                 ("sample_m", C.c_uint32), ("rand_jitter", c_fp * NLR_MAX_LEVELS), ("rand_deg", c_fp * NLR_MAX_LEVELS),
-                ("scale_factor", C.c_float)]
+                ("scale_factor", C.c_float), ("shuffled_rays", C.c_uint32)]
 
 
 class NlrLevelOut(C.Structure):
@@ -89,7 +89,7 @@ EXPORTS = ["nlr_last_error", "nlr_version", "nlr_build_sha", "nlr_debug_set", "n
            "nlr_train_plan_create", "nlr_train_plan_destroy", "nlr_train_act_width", "nlr_train_param_layout", "nlr_train_pack",
            "nlr_mlp_train_forward", "nlr_mlp_train_backward"]
 NLR_K_COUNT = 6
-DBG_FORCE_GENERIC, DBG_MLP_WORKGROUPS, DBG_BINNED_C4, DBG_NO_XPAIR_SCATTER, DBG_SCATTER_LEVELS, DBG_NO_SCATTER_CACHE = 0, 1, 2, 3, 4, 5
+DBG_FORCE_GENERIC, DBG_MLP_WORKGROUPS, DBG_BINNED_C4, DBG_NO_XPAIR_SCATTER, DBG_SCATTER_LEVELS, DBG_NO_SCATTER_CACHE, DBG_RAY_GROUPS = 0, 1, 2, 3, 4, 5, 6
 
 
 def lib():

@@ -47,6 +47,9 @@ class Model:
         self.device = torch.device(device)
         self.precision = precision
         self.training = False
+        # performance hint (NlrRenderCfg.shuffled_rays, no effect on results): False = consecutive rays of a batch are neighbours in
+        # space (sweeps, image tiles), the encode kernels then walk 8 adjacent rays together; True for shuffled batches
+        self.shuffled_rays = False
         self.num_levels = mc.num_levels
         self.tables: Dict[str, torch.Tensor] = {}
         self._keep = []  # host arrays referenced by the descriptor during nlr_model_create
@@ -233,6 +236,7 @@ class Model:
         cfg.compute_extras = int(compute_extras)
         cfg.sample_n, cfg.sample_m = sample_n, sample_m
         cfg.scale_factor = float(scale_factor)
+        cfg.shuffled_rays = int(bool(getattr(self, "shuffled_rays", False)))
         for li in range(len(samples)):
             if rand_jitter is not None:
                 t = rand_jitter[li].reshape(n).contiguous().float()

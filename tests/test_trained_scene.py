@@ -177,3 +177,31 @@ def test_trained_full_sweep_against_oracle(gpu_models, case):
     print(msg)
     assert d.max() <= 1e-3 and i.max() <= 1e-3, msg
     assert not (lab & (margin > 1e-3)).any(), msg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,width", [("C2", 256), ("REFI", 67)])
+def test_wave_order_of_the_encode_kernels_does_not_change_the_render(gpu_models, case, width):
+    """Which samples share a wave of the fused cast + encode kernels (8 adjacent rays at one sample index, 8 consecutive samples of one ray,
+    or the per-level decision the device takes from the coherence of adjacent rays: `NlrRenderCfg.shuffled_rays`, NLR_DBG_RAY_GROUPS) is a
+    performance choice: every output is bit-identical.  width 67: 32 x 67 = 2 144 rays = 268 groups of 8 (REFI), and the 820-ray fixtures
+    above (102.5 groups) take the default path through the padded last group."""
+    from nerflidar_hip import _lib
+    model = gpu_models[(case, 2)]
+    b = nlidar.synthetic_sweep(width=width, seed=0, sweep_idx=100)
+    if case == "REFI":   # a ray count that is not a multiple of 8
+        b = {k: np.ascontiguousarray(v[:-3]) for k, v in b.items()}
+    tb = {k: T(v).cuda() for k, v in b.items()}
+    outs = {}
+    try:
+        for name, key, shuffled in (("auto", 0, False), ("rays", 1, False), ("samples", 2, False), ("hint", 0, True)):
+            _lib.lib().nlr_debug_set(_lib.DBG_RAY_GROUPS, key)
+            model.shuffled_rays = shuffled
+            r, hist = model.render_rays(tb, scale_factor=1 / 250, want_history=True)
+            outs[name] = {k: v.clone() for k, v in r.items()} | {f"w{l}": h["weights"].clone() for l, h in enumerate(hist)}
+    finally:
+        _lib.lib().nlr_debug_set(_lib.DBG_RAY_GROUPS, 0)
+        model.shuffled_rays = False
+    for name in ("rays", "samples", "hint"):
+        for k, v in outs["auto"].items():
+            assert torch.equal(v, outs[name][k]), (name, k)
