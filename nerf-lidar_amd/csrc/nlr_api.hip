@@ -612,7 +612,7 @@ static int render_impl(const NlrModel *m, const NlrRays *rays, uint32_t N, const
     Carve c(workspace, workspace_bytes - obj_ws);
     const uint32_t n = cfg->sample_n ? cfg->sample_n : 7, mloops = cfg->sample_m ? cfg->sample_m : 3;
     uint32_t *votes = (uint32_t *)c.take(64);  // per level: coherent (adjacent rays, sample) pairs, see nlr_slot_sample
-    NLR_HIP(hipMemsetAsync(votes, 0, 64 * sizeof(uint32_t), st));
+    if (int rc0 = nlr_launch_ray_vote(nullptr, 0, 0, votes, st)) return rc0;  // zero the counters (a kernel: a memset node slows a captured graph down)
 
     const float *prev_s = nullptr, *prev_w = nullptr;
     uint32_t n_prev = 0;

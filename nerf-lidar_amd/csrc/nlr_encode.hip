@@ -220,7 +220,14 @@ __global__ void __launch_bounds__(256) nlr_ray_vote_kernel(const float *__restri
         if (c) atomicAdd(votes, c);
     }
 }
+__global__ void nlr_ray_vote_zero_kernel(uint32_t *votes) { votes[threadIdx.x] = 0u; }
+// tdist == NULL: zero the 64 counters of a render (before its first level)
 int nlr_launch_ray_vote(const float *tdist, uint32_t N, uint32_t S, uint32_t *votes, hipStream_t st) {
+    if (!tdist) {
+        hipLaunchKernelGGL(nlr_ray_vote_zero_kernel, dim3(1), dim3(64), 0, st, votes);
+        NLR_LAUNCH_CHECK("nlr_ray_vote_zero_kernel");
+        return NLR_OK;
+    }
     if (N < 2 || S == 0) return NLR_OK;
     NLR_CHECK_ARG((uint64_t)N * S < (1ull << 32), "ray vote: N * S = %llu does not fit 32 bits", (unsigned long long)N * S);
     const uint32_t nb = ((N - 1) * S + 255) / 256;
